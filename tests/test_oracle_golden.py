@@ -1,0 +1,116 @@
+"""CPU: pin the numpy oracle against golden vectors produced by the reference
+itself (tests/golden/make_golden.py).  Tolerances are float32 round-off of two
+different BLAS/libm stacks (torch vs numpy): 2e-5 relative on variances."""
+import numpy as np
+import pytest
+
+import vaenmf_oracle as orc
+from helpers import load_case, rel_err, nrm_err, GOLDEN
+
+CASES = [("m1_f65", "M1"), ("m2_vad_f65", "M2"), ("m2_ibm_f65", "M2"), ("m1_f257", "M1")]
+
+
+def run_oracle(name, model):
+    z, params, draws, meta = load_case(name)
+    nsE, biE, nsW, biW = meta["counts"]
+    m = orc.MCEMOracle(model, meta["niter"], nsE, biE, nsW, biW, 0.01, reference_compat=True)
+    rng = orc.ReplayRNG(draws)
+    y = z["y"] if model == "M2" else None
+    m.init_parameters(z["X"], params, meta["K"], 1e-8, rng, y=y)
+    return z, m, rng
+
+
+@pytest.mark.parametrize("name,model", CASES)
+def test_init_matches_reference(name, model):
+    z, m, _ = run_oracle(name, model)
+    assert rel_err(m.W, z["W0"]) == 0 and rel_err(m.H, z["H0"]) == 0
+    assert np.max(np.abs(m.Z - z["Z0"])) < 2e-5
+
+
+@pytest.mark.parametrize("name,model", CASES)
+def test_first_iteration_steps(name, model):
+    """E-step (MH log-acceptance of every step, decisions, Vs, Vx) then M-step."""
+    z, m, rng = run_oracle(name, model)
+    trace = []
+    ns, bi = m.e_step_counts()
+    Zs = m.sample_posterior(m.Z, ns, bi, trace=trace)
+    n1 = int(z["E1_nacc"])
+    assert len(trace) == n1 == ns + bi
+    acc = np.stack([t["acc"] for t in trace])
+    assert np.max(np.abs(acc - z["acc"][:n1])) < 2e-3 * max(1.0, np.abs(z["acc"][:n1]).max() * 1e-2)
+    m.Z = Zs[:, -1, :].T.copy()
+    m.compute_Vs(Zs); m.compute_Vs_scaled(); m.compute_Vx()
+    assert np.max(np.abs(m.Z - z["E1_Z"])) < 1e-5
+    assert rel_err(m.Vs, z["E1_Vs"]) < 2e-5
+    assert rel_err(m.Vx, z["E1_Vx"]) < 2e-5
+    m.M_step()
+    for k, v in (("M1_W", m.W), ("M1_H", m.H), ("M1_g", m.g), ("M1_Vb", m.Vb), ("M1_Vx", m.Vx)):
+        assert rel_err(v, z[k]) < 5e-5, k
+
+
+@pytest.mark.parametrize("name,model", CASES)
+def test_full_run(name, model):
+    z, m, rng = run_oracle(name, model)
+    cost = m.run()
+    assert rng.pos == len(rng.draws)          # same number and order of random draws
+    assert cost.dtype == np.float64 and cost.shape == (m.niter,)
+    assert np.max(np.abs(cost - z["cost"]) / np.abs(z["cost"])) < 2e-5
+    assert tuple(m.Vs.shape) == tuple(z["Vs_shape"])
+    for k, v in (("W", m.W), ("H", m.H), ("g", m.g)):
+        assert rel_err(v, z[k]) < 2e-4, k
+    assert np.max(np.abs(m.Z - z["Z"])) < 2e-5
+    assert rel_err(m.WFs, z["WFs"]) < 2e-4 and rel_err(m.WFn, z["WFn"]) < 2e-4
+    assert nrm_err(m.S_hat, z["S_hat"]) < 1e-5 and nrm_err(m.N_hat, z["N_hat"]) < 1e-5
+    assert m.S_hat.dtype == np.complex64
+
+
+def test_quirk_counts():
+    """mcem.py:371 vs :461-462/:477-478 -- M1's positional shift."""
+    q = np.load(GOLDEN + "/quirk_counts.npz")
+    m1 = orc.MCEMOracle("M1", 1)
+    m2 = orc.MCEMOracle("M2", 1)
+    (r, b), (rw, bw) = m1.e_step_counts(), m1.wf_counts()
+    assert (r + b, r, rw + bw, rw) == tuple(q["M1"])
+    (r, b), (rw, bw) = m2.e_step_counts(), m2.wf_counts()
+    assert (r + b, r, rw + bw, rw) == tuple(q["M2"])
+    assert orc.MCEMOracle("M1", 1, reference_compat=False).e_step_counts() == (10, 30)
+
+
+def test_mlp_forward():
+    z = np.load(GOLDEN + "/mlp_forward.npz")
+    for tag in ("m1", "m2"):
+        p = {k.split(":p:")[1]: z[k] for k in z.files if k.startswith(tag + ":p:")}
+        zz, mu, lv = orc.encoder_forward(p, z[tag + "_x"], z[tag + "_eps"])
+        assert np.max(np.abs(mu - z[tag + "_mu"])) < 1e-5
+        assert np.max(np.abs(lv - z[tag + "_lv"])) < 1e-5
+        assert np.max(np.abs(zz - z[tag + "_zz"])) < 1e-5
+        assert rel_err(orc.decoder_forward(p, z[tag + "_z"]), z[tag + "_dec"]) < 1e-5
+    p = {k.split(":p:")[1]: z[k] for k in z.files if k.startswith("clf:p:")}
+    assert np.max(np.abs(orc.classifier_forward(p, z["clf_x"]) - z["clf_y"])) < 1e-6
+
+
+def test_energy_ratios_known_answer():
+    """python/metrics.py:39-60 on the reference-committed dummy-M2 wavs; the
+    reference's own figure title for 440c020a reads -6.2 / -4.3 / -1.9 dB."""
+    z = np.load(GOLDEN + "/metrics_dummy_m2.npz")
+    r = orc.energy_ratios(z["a_s_est"] / 32768.0, z["a_s"] / 32768.0, z["a_n"] / 32768.0)
+    assert np.allclose(r, z["a_ratios"], rtol=0, atol=1e-9)
+    assert [round(float(v), 1) for v in r] == [-6.2, -4.3, -1.9]
+
+
+def test_stft_roundtrip_and_shapes():
+    """stft.py:48-53 end-pad rule + librosa framing; istft(stft(x)) == x."""
+    z = np.load(GOLDEN + "/metrics_dummy_m2.npz")
+    x = z["a_s"] / 32768.0
+    X = orc.stft(x, fs=16000, wlen_sec=64e-3, hop_percent=0.25)
+    assert X.dtype == np.complex64 and X.shape[0] == 513
+    T = len(x)
+    need_pad = int(np.ceil(T / 16000 / 64e-3 / 0.25)) != int(T / 16000 / 64e-3 / 0.25)
+    assert X.shape[1] == 1 + (T + (256 if need_pad else 0)) // 256
+    xr = orc.istft(X, fs=16000, wlen_sec=64e-3, hop_percent=0.25, max_len=T)
+    assert xr.dtype == np.float32 and len(xr) == T
+    assert np.max(np.abs(xr - x)) < 1e-6
+    Xa = orc.stft(np.zeros(64000), fs=16000, wlen_sec=32e-3)
+    assert Xa.shape == (257, 501)
+    with pytest.raises(ValueError):
+        orc.stft(x, fs=16000, wlen_sec=50.01e-3)
