@@ -1,0 +1,389 @@
+// Small kernels around the hot loop: W multiplicative update, cost reduction,
+// dense layers (encoder / classifier), |X|^2, STFT / iSTFT, SI-SDR Gram sums.
+#include "common.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// W update (mcem.py:107-110) + L1 column normalisation (mcem.py:129-133).
+// One workgroup per utterance: num[f,k] = sum_n P[n,f] H[k,n], den[f,k] = sum_n A1[n,f] H[k,n]
+// with P = X2 * sum_r Vx^-2 and A1 = sum_r Vx^-1 produced by decode_kernel<MODE_WSTATS>.
+// ----------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(1024) void w_update_kernel(const float* __restrict__ A1, const float* __restrict__ P,
+                                                        const float* __restrict__ Ht, float* __restrict__ W,
+                                                        float* __restrict__ normW, const int32_t* __restrict__ frame_off,
+                                                        int F, int Fs, int K, int FL, int NG) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);            // [FL][2*KP]
+  float* colred = red + (size_t)FL * 2 * KP;              // [32 waves][KP]
+  const int u = blockIdx.x;
+  const int f = threadIdx.x % FL, ng = threadIdx.x / FL;
+  const int nb = frame_off[u], ne = frame_off[u + 1];
+  float num[KP], den[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) num[k] = den[k] = 0.f;
+  if (ng < NG && f < Fs) {
+    for (int n = nb + ng; n < ne; n += NG) {
+      const float pv = P[(size_t)n * Fs + f], av = A1[(size_t)n * Fs + f];
+#pragma unroll
+      for (int k = 0; k < KP; k += 4) {
+        const f32x4 h = *reinterpret_cast<const f32x4*>(Ht + (size_t)n * KP + k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { num[k + t] += pv * h[t]; den[k + t] += av * h[t]; }
+      }
+    }
+  }
+  // deterministic reduction over the NG frame groups (fixed order)
+  for (int r = 0; r < NG; ++r) {
+    if (ng == r && f < Fs) {
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        if (r == 0) { red[f * 2 * KP + 2 * k] = num[k]; red[f * 2 * KP + 2 * k + 1] = den[k]; }
+        else        { red[f * 2 * KP + 2 * k] += num[k]; red[f * 2 * KP + 2 * k + 1] += den[k]; }
+      }
+    }
+    __syncthreads();
+  }
+  float wn[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) wn[k] = 0.f;
+  if (ng == 0 && f < F) {
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+      if (k < K) {
+        const float w0 = W[((size_t)u * Fs + f) * KP + k];
+        wn[k] = w0 * sqrtf(red[f * 2 * KP + 2 * k] / red[f * 2 * KP + 2 * k + 1]);     // mcem.py:110
+      }
+  }
+  // column L1 norms (mcem.py:129): wave shuffle reduction, then across waves
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    float v = fabsf(wn[k]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0) colred[wv * KP + k] = v;
+  }
+  __syncthreads();
+  const int nwv = blockDim.x >> 6;
+  float nrm[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    float s = 0.f;
+    for (int ww = 0; ww < nwv; ++ww) s += colred[ww * KP + k];
+    nrm[k] = s;
+  }
+  if (ng == 0 && f < Fs) {
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+      W[((size_t)u * Fs + f) * KP + k] = (k < K && f < F) ? wn[k] / nrm[k] : 0.f;        // mcem.py:131
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < KP; ++k) normW[(size_t)u * KP + k] = (k < K) ? nrm[k] : 0.f;    // applied to H (mcem.py:133)
+  }
+}
+
+// cost[u][it] = mean_{r,f,n}(log Vx + X2/Vx)  (mcem.py:70) from per-frame sums
+__global__ void cost_reduce_kernel(const double* __restrict__ cost_frames, const int32_t* __restrict__ frame_off,
+                                   int R, int F, double* __restrict__ cost, int niter, int it) {
+  __shared__ double red[256];
+  const int u = blockIdx.x;
+  const int nb = frame_off[u], ne = frame_off[u + 1];
+  double s = 0.0;
+  for (int n = nb + threadIdx.x; n < ne; n += blockDim.x) s += cost_frames[n];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int m = 128; m >= 1; m >>= 1) {
+    if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cost[(size_t)u * niter + it] = red[0] / ((double)R * F * (ne - nb));
+}
+
+// ----------------------------------------------------------------------------
+// Dense layer Y = act(X Wt^T + b), fp32 FMA, 64x64 output tile, K-step 16.
+// (encoder / classifier: once per utterance, models.py:101-104, 57-62)
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case VAENMF_ACT_TANH: return tanhf(v);
+    case VAENMF_ACT_RELU: return fmaxf(v, 0.f);
+    case VAENMF_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+__global__ __launch_bounds__(256) void dense_kernel(const float* __restrict__ X, int M, int in, int ldx,
+                                                    const float* __restrict__ Wt, const float* __restrict__ b, int out,
+                                                    int act, float* __restrict__ Y, int ldy) {
+  __shared__ float xs[16][65], ws[16][65];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * 64, o0 = blockIdx.x * 64;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < in; k0 += 16) {
+    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+      const int r = e >> 4, kk = e & 15;
+      xs[kk][r] = (m0 + r < M && k0 + kk < in) ? X[(size_t)(m0 + r) * ldx + k0 + kk] : 0.f;
+      ws[kk][r] = (o0 + r < out && k0 + kk < in) ? Wt[(size_t)(o0 + r) * in + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float xv[4], wv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { xv[i] = xs[kk][ty * 4 + i]; wv[i] = ws[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += xv[i] * wv[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + ty * 4 + i, o = o0 + tx * 4 + j;
+      if (m < M && o < out) Y[(size_t)m * ldy + o] = apply_act(acc[i][j] + (b ? b[o] : 0.f), act);
+    }
+}
+
+__global__ void power_spec_kernel(const float2* __restrict__ X, float* __restrict__ X2, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float2 v = X[i]; X2[i] = v.x * v.x + v.y * v.y; }
+}
+
+// ----------------------------------------------------------------------------
+// STFT / iSTFT (python/processing/stft.py -> librosa): radix-2 FFT in LDS, fp64.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ int bitrev(int x, int bits) { return (int)(__brev((unsigned)x) >> (32 - bits)); }
+
+// in-place complex FFT of length n (power of two) on LDS arrays; sign = -1 forward, +1 inverse
+__device__ void fft_lds(double* re, double* im, const double* twr, const double* twi, int n, int bits, int sign) {
+  for (int len = 2, st = n >> 1; len <= n; len <<= 1, st >>= 1) {
+    const int half = len >> 1;
+    for (int b = threadIdx.x; b < (n >> 1); b += blockDim.x) {
+      const int grp = b / half, pos = b - grp * half;
+      const int i0 = grp * len + pos, i1 = i0 + half;
+      const double wr = twr[pos * st], wi = sign * twi[pos * st];
+      const double xr = re[i1] * wr - im[i1] * wi, xi = re[i1] * wi + im[i1] * wr;
+      re[i1] = re[i0] - xr; im[i1] = im[i0] - xi;
+      re[i0] += xr;         im[i0] += xi;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav, const int64_t* __restrict__ samp_off,
+                                                   const int32_t* __restrict__ frame_off, const int32_t* __restrict__ frame_utt,
+                                                   const int32_t* __restrict__ pad_len, int nfft, int bits, int hop, int Fs,
+                                                   float2* __restrict__ X) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* re = reinterpret_cast<double*>(smem);
+  double* im = re + nfft;
+  double* twr = im + nfft;
+  double* twi = twr + nfft / 2;
+  const int n = blockIdx.x, u = frame_utt[n], i = n - frame_off[u];
+  const int64_t off = samp_off[u];
+  const int64_t T = samp_off[u + 1] - off;
+  const int64_t Tp = pad_len[u];                 // length after the end-pad rule (stft.py:48-53)
+  for (int t = threadIdx.x; t < nfft / 2; t += blockDim.x) {
+    double s, c;
+    sincospi(-2.0 * t / nfft, &s, &c);           // exp(-2 pi i t / nfft)
+    twr[t] = c; twi[t] = s;
+  }
+  for (int t = threadIdx.x; t < nfft; t += blockDim.x) {
+    int64_t p = (int64_t)i * hop + t - nfft / 2;  // centre=True, reflect padding
+    if (p < 0) p = -p;
+    if (p >= Tp) p = 2 * (Tp - 1) - p;
+    const double v = (p >= 0 && p < T) ? (double)wav[off + p] : 0.0;
+    double sw, cw;
+    sincospi(2.0 * t / nfft, &sw, &cw);
+    const int r = bitrev(t, bits);
+    re[r] = v * (0.5 - 0.5 * cw);                 // periodic Hann
+    im[r] = 0.0;
+  }
+  __syncthreads();
+  fft_lds(re, im, twr, twi, nfft, bits, 1);       // table holds exp(-i..): sign +1 keeps it
+  const int F = nfft / 2 + 1;
+  for (int f = threadIdx.x; f < Fs; f += blockDim.x)
+    X[(size_t)n * Fs + f] = f < F ? make_float2((float)re[f], (float)im[f]) : make_float2(0.f, 0.f);
+}
+
+__global__ __launch_bounds__(256) void istft_frames_kernel(const float2* __restrict__ S, int nfft, int bits, int Fs,
+                                                           float* __restrict__ work) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* re = reinterpret_cast<double*>(smem);
+  double* im = re + nfft;
+  double* twr = im + nfft;
+  double* twi = twr + nfft / 2;
+  const int n = blockIdx.x;
+  for (int t = threadIdx.x; t < nfft / 2; t += blockDim.x) {
+    double s, c;
+    sincospi(2.0 * t / nfft, &s, &c);             // exp(+2 pi i t / nfft)
+    twr[t] = c; twi[t] = s;
+  }
+  const int half = nfft / 2;
+  for (int k = threadIdx.x; k < nfft; k += blockDim.x) {
+    const int kk = k <= half ? k : nfft - k;
+    const float2 v = S[(size_t)n * Fs + kk];
+    double vr = v.x, vi = (k <= half) ? v.y : -v.y;
+    if (k == 0 || k == half) vi = 0.0;            // c2r ignores the imaginary part of DC / Nyquist
+    const int r = bitrev(k, bits);
+    re[r] = vr; im[r] = vi;
+  }
+  __syncthreads();
+  fft_lds(re, im, twr, twi, nfft, bits, 1);
+  for (int t = threadIdx.x; t < nfft; t += blockDim.x) {
+    double sw, cw;
+    sincospi(2.0 * t / nfft, &sw, &cw);
+    work[(size_t)n * nfft + t] = (float)(re[t] / nfft * (0.5 - 0.5 * cw));
+  }
+}
+
+__global__ void istft_ola_kernel(const float* __restrict__ work, const int64_t* __restrict__ samp_off,
+                                 const int32_t* __restrict__ frame_off, int n_utt, int nfft, int hop,
+                                 float* __restrict__ out) {
+  const int u = blockIdx.y;
+  const int64_t off = samp_off[u], T = samp_off[u + 1] - off;
+  const int nb = frame_off[u], nfr = frame_off[u + 1] - nb;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t + nfft / 2;
+    float y = 0.f;
+    double wss = 0.0;
+    if (p < (int64_t)nfft + (int64_t)hop * (nfr - 1)) {
+      int64_t i_lo = (p - nfft + hop) / hop;        // ceil((p - nfft + 1)/hop)
+      if (p - nfft + 1 <= 0) i_lo = 0;
+      int64_t i_hi = p / hop;
+      if (i_hi > nfr - 1) i_hi = nfr - 1;
+      for (int64_t i = i_lo; i <= i_hi; ++i) {
+        const int tt = (int)(p - i * hop);
+        double sw, cw;
+        sincospi(2.0 * tt / nfft, &sw, &cw);
+        const double wv = 0.5 - 0.5 * cw;
+        y += work[(size_t)(nb + i) * nfft + tt];
+        wss += wv * wv;
+      }
+      if (wss > 1.1754943508222875e-38) y = (float)(y / wss);
+    }
+    out[off + t] = y;
+  }
+}
+
+// Gram matrix of (s_hat, s, n) per utterance in float64 (python/metrics.py:12-60)
+__global__ __launch_bounds__(256) void gram3_kernel(const float* __restrict__ sh, const float* __restrict__ s,
+                                                    const float* __restrict__ nz, const int64_t* __restrict__ samp_off,
+                                                    double* __restrict__ out) {
+  __shared__ double red[6][256];
+  const int u = blockIdx.x;
+  const int64_t b = samp_off[u], e = samp_off[u + 1];
+  double a[6] = {0, 0, 0, 0, 0, 0};
+  for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+    const double x = sh[i], y = s[i], z = nz[i];
+    a[0] += x * x; a[1] += x * y; a[2] += x * z; a[3] += y * y; a[4] += y * z; a[5] += z * z;
+  }
+  for (int j = 0; j < 6; ++j) red[j][threadIdx.x] = a[j];
+  __syncthreads();
+  for (int m = 128; m >= 1; m >>= 1) {
+    if ((int)threadIdx.x < m)
+      for (int j = 0; j < 6; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) out[(size_t)u * 6 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+int ilog2(int n) { int b = 0; while ((1 << b) < n) ++b; return b; }
+
+}  // namespace
+
+int vn_launch_w_update(const vaenmf_plan* p, float* W, const float* Ht, hipStream_t st) {
+  const int FL = ((p->Fs + 63) / 64) * 64;
+  int NG = 1024 / FL;
+  if (NG < 1) { vaenmf_set_error("Fs=%d too large for w_update", p->Fs); return -1; }
+  if (NG > 4) NG = 4;
+  const int threads = FL * NG;
+  const size_t lds = ((size_t)FL * 2 * p->Kp + 32 * p->Kp) * sizeof(float);
+#define VN_WU(KP)                                                                                              \
+  do {                                                                                                         \
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)w_update_kernel<KP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((w_update_kernel<KP>), dim3(p->n_utt), dim3(threads), lds, st, p->A1, p->P, Ht, W, p->normW, \
+                       p->d_frame_off, p->cfg.F, p->Fs, p->cfg.K, FL, NG);                                      \
+  } while (0)
+  switch (p->Kp) { case 8: VN_WU(8); break; case 16: VN_WU(16); break; default: VN_WU(32); break; }
+#undef VN_WU
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int vn_launch_cost_reduce(const vaenmf_plan* p, const double* cost_frames, int R, double* cost, int niter, int it, hipStream_t st) {
+  hipLaunchKernelGGL(cost_reduce_kernel, dim3(p->n_utt), dim3(256), 0, st, cost_frames, p->d_frame_off, R, p->cfg.F, cost, niter, it);
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vaenmf_dense(const float* X, int32_t M, int32_t in, int32_t ldx, const float* Wt, const float* b,
+                            int32_t out, int32_t act, float* Y, int32_t ldy, void* stream) {
+  VN_REQUIRE(X && Wt && Y && M > 0 && in > 0 && out > 0, "vaenmf_dense: bad arguments");
+  hipLaunchKernelGGL(dense_kernel, dim3((out + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, X, M, in, ldx,
+                     Wt, b, out, act, Y, ldy);
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vaenmf_power_spec(const float* X, float* X2, int64_t n, void* stream) {
+  VN_REQUIRE(X && X2 && n > 0, "vaenmf_power_spec: bad arguments");
+  hipLaunchKernelGGL(power_spec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float2*>(X), X2, n);
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vaenmf_stft_num_frames(int64_t n_samples, double fs, double wlen_sec, double hop_percent, int32_t* nfft,
+                                      int32_t* hop, int32_t* n_frames, int32_t* n_padded) {
+  VN_REQUIRE(wlen_sec * fs == (double)(int64_t)(wlen_sec * fs), "wlen_sample of STFT is not an integer.");  // stft.py:37-38
+  const int nf = (int)(wlen_sec * fs);
+  const int hp = (int)(hop_percent * nf);
+  VN_REQUIRE(nf >= 16 && nf <= 2048 && (nf & (nf - 1)) == 0, "n_fft=%d: this build needs a power of two in [16,2048]", nf);
+  VN_REQUIRE(hp > 0, "hop must be positive");
+  const double utt_len = (double)n_samples / fs;                                                            // stft.py:49
+  const double ratio = utt_len / wlen_sec / hop_percent;
+  int64_t Tp = n_samples;
+  if (ceil(ratio) != (double)(int64_t)ratio) Tp += hp;                                                      // stft.py:50-51
+  *nfft = nf; *hop = hp; *n_padded = (int32_t)Tp; *n_frames = (int32_t)(1 + Tp / hp);
+  return 0;
+}
+
+extern "C" int vaenmf_stft_batch(const float* wav, int32_t n_frames_total, const int64_t* sample_offsets,
+                                 const int32_t* frame_offsets, const int32_t* frame_utt, const int32_t* padded_len,
+                                 int32_t nfft, int32_t hop, int32_t Fs, float* X, void* stream) {
+  VN_REQUIRE(wav && X && n_frames_total > 0, "vaenmf_stft_batch: bad arguments");
+  VN_REQUIRE((nfft & (nfft - 1)) == 0 && nfft <= 2048 && Fs >= nfft / 2 + 1, "vaenmf_stft_batch: bad nfft/Fs");
+  const size_t lds = (size_t)nfft * 3 * sizeof(double);
+  hipLaunchKernelGGL(stft_kernel, dim3(n_frames_total), dim3(256), lds, (hipStream_t)stream, wav, sample_offsets,
+                     frame_offsets, frame_utt, padded_len, nfft, ilog2(nfft), hop, Fs, reinterpret_cast<float2*>(X));
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vaenmf_istft_batch(const float* S, int32_t n_utt, int32_t n_frames_total, const int64_t* sample_offsets,
+                                  const int32_t* frame_offsets, int32_t nfft, int32_t hop, int32_t Fs, float* work,
+                                  float* wav_out, void* stream) {
+  VN_REQUIRE(S && work && wav_out && n_utt > 0, "vaenmf_istft_batch: bad arguments");
+  VN_REQUIRE((nfft & (nfft - 1)) == 0 && nfft <= 2048 && Fs >= nfft / 2 + 1, "vaenmf_istft_batch: bad nfft/Fs");
+  const size_t lds = (size_t)nfft * 3 * sizeof(double);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(istft_frames_kernel, dim3(n_frames_total), dim3(256), lds, st, reinterpret_cast<const float2*>(S), nfft,
+                     ilog2(nfft), Fs, work);
+  hipLaunchKernelGGL(istft_ola_kernel, dim3(64, n_utt), dim3(256), 0, st, work, sample_offsets, frame_offsets, n_utt, nfft, hop, wav_out);
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vaenmf_gram3_batch(const float* s_hat, const float* s, const float* n, int32_t n_utt,
+                                  const int64_t* sample_offsets, double* out, void* stream) {
+  VN_REQUIRE(s_hat && s && n && out && n_utt > 0, "vaenmf_gram3_batch: bad arguments");
+  hipLaunchKernelGGL(gram3_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, s_hat, s, n, sample_offsets, out);
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}

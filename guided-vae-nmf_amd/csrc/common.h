@@ -1,0 +1,124 @@
+// Shared declarations for libvaenmf.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/vaenmf.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- host side -------------------------------------------------------------
+void vaenmf_set_error(const char* fmt, ...);
+#define VN_CHECK_HIP(expr)                                                         \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      vaenmf_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return -2;                                                                   \
+    }                                                                              \
+  } while (0)
+#define VN_REQUIRE(cond, ...)                \
+  do {                                       \
+    if (!(cond)) {                           \
+      vaenmf_set_error(__VA_ARGS__);         \
+      return -1;                             \
+    }                                        \
+  } while (0)
+
+constexpr int FRAMES_PER_TILE = 32;   // MH chain: frames per workgroup (2 MFMA column groups of 16)
+constexpr int MAXT = 5;               // feature tiles (16 bins each) per wave in the last layer
+constexpr int LAT = 32;               // latent dimension handled by the MFMA path
+constexpr int HID = 128;              // hidden width of both decoder layers
+
+struct vaenmf_plan {
+  vaenmf_config cfg;
+  int Fs, Kp, NT3;           // padded bins, padded rank, feature tiles of 16 in the last layer
+  int nwaves;                // waves per workgroup that split the features (4: F<=320, 8: F<=640)
+  // decoder weights on the device, MFMA fragment order (see weights in plan.hip)
+  __bf16 *w1f, *w2f, *w3f;   // [tile][kstep][part hi/lo][lane][8]
+  float *b1, *b2, *b3;       // biases (b3 padded to 16*NT3)
+  float* w1y;                // [H1][Dy] label columns of W1 (M2)
+  int Dy;
+  bool have_weights;
+  // bound batch
+  int n_utt, NT, n_tiles;
+  int32_t *d_frame_off;      // [n_utt+1]
+  int32_t *d_tile_utt, *d_tile_n0, *d_tile_cnt;   // MH-chain tiles (<=32 frames, one utterance each)
+  int32_t *d_frame_utt;      // [NT]
+  int32_t *d_frame_loc;      // [NT] frame index inside its utterance
+  uint64_t* d_utt_seed;      // [n_utt]
+  std::vector<int32_t> h_frame_off;
+  // workspace
+  float *A1, *P;             // [NT][Fs] W-update statistics
+  float* normW;              // [n_utt][Kp]
+  double* cost_frames;       // [NT] (fused driver)
+  int n_sms;
+};
+
+// ---- device helpers --------------------------------------------------------
+#if defined(__HIPCC__)
+__device__ __forceinline__ float fast_tanh(float x) {
+  // tanh(x) = 1 - 2/(exp(2x)+1); exp via v_exp_f32 (2^x).  abs error ~2e-7.
+  float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// split 4 floats into bf16 hi and lo parts: v ~= hi + lo (error ~2^-17 |v|)
+__device__ __forceinline__ void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    __bf16 h = (__bf16)v[t];
+    hi[t] = h;
+    lo[t] = (__bf16)(v[t] - (float)h);
+  }
+}
+
+// xoshiro128+ : per-lane stream, 32 random bits per call, no multiplies
+struct Xs128 {
+  uint32_t s0, s1, s2, s3;
+  __device__ __forceinline__ uint32_t next() {
+    uint32_t r = s0 + s3;
+    uint32_t t = s1 << 9;
+    s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t;
+    s3 = (s3 << 11) | (s3 >> 21);
+    return r;
+  }
+};
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t& x) {
+  uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// stream key: (utterance seed, frame index inside the utterance, sub-stream id, chain call)
+__device__ __forceinline__ Xs128 xs_seed(uint64_t utt_seed, uint32_t frame, uint32_t sub, uint32_t call) {
+  uint64_t x = utt_seed ^ (((uint64_t)frame << 32) | ((uint64_t)sub << 24) | (uint64_t)(call & 0xFFFFFFu));
+  x ^= (uint64_t)(call >> 24) << 56;
+  uint64_t a = splitmix64(x), b = splitmix64(x);
+  Xs128 s;
+  s.s0 = (uint32_t)a; s.s1 = (uint32_t)(a >> 32); s.s2 = (uint32_t)b; s.s3 = (uint32_t)(b >> 32);
+  if ((s.s0 | s.s1 | s.s2 | s.s3) == 0) s.s0 = 1;
+  return s;
+}
+// 4 standard normals from 4 random words (two Box-Muller pairs); v_sin/v_cos take revolutions.
+__device__ __forceinline__ f32x4 normal4(Xs128& st) {
+  f32x4 o;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    uint32_t a = st.next(), b = st.next();
+    float u1 = ((float)(a >> 8) + 1.0f) * 5.9604644775390625e-8f;   // (0,1]
+    float u2 = (float)(b >> 8) * 5.9604644775390625e-8f;            // [0,1)
+    float r = __builtin_amdgcn_sqrtf(-2.0f * fast_log(u1));
+    o[2 * p] = r * __builtin_amdgcn_cosf(u2);
+    o[2 * p + 1] = r * __builtin_amdgcn_sinf(u2);
+  }
+  return o;
+}
+__device__ __forceinline__ float uniform01(Xs128& st) { return (float)(st.next() >> 8) * 5.9604644775390625e-8f; }
+#endif

@@ -1,0 +1,873 @@
+// MH-chain and sample-decode kernels: the hot loop of the VAE-NMF reconstruct path.
+//
+// Both kernels evaluate the decoder MLP (python/models/models.py:118-121) on MFMA
+// (v_mfma_f32_16x16x32_bf16, fp32 accumulate).  The MLP input rows are the MFMA
+// *column* dimension (16 per column group), the features are MFMA rows split over
+// the waves of a workgroup, so an accumulator tile of one layer is, after tanh and a
+// bf16 (hi,lo) split, directly the B fragment of the next layer (exchanged between
+// waves through LDS in fragment order -- no transposes, no shuffles).
+//
+//   fragment order: k-step s of 32 input features, lane (q = lane>>4, c = lane&15),
+//   element j (0..7)  <->  input feature  phi(s,q,j) = 32 s + 16 (j>>2) + 4 q + (j&3)
+//   (a 16x16 accumulator tile T holds rows 4q+t of feature tile T in lane group q,
+//   so k-step s consumes feature tiles 2s (j<4) and 2s+1 (j>=4)).  The weights are
+//   pre-permuted on the host into the same order (plan.hip: pack_weights).
+//
+// PREC: bf16x3 computes w_hi*a_hi + w_lo*a_hi + w_hi*a_lo (error ~2^-17 per product);
+//       bf16 computes w_hi*a_hi only.
+#include "common.h"
+
+namespace {
+
+constexpr int NK_H = HID / 32;     // k-steps over a hidden layer (4)
+constexpr int NT_H = HID / 16;     // feature tiles of a hidden layer (8)
+
+struct DecW {                      // decoder weights (device), fragment order
+  const __bf16 *w1f, *w2f, *w3f;
+  const float *b1, *b2, *b3;
+  int NT3;                         // feature tiles in the last layer
+  int F;
+};
+
+__device__ __forceinline__ bf16x8 ldw(const __bf16* base, int tile, int nk, int s, int part, int lane) {
+  return *reinterpret_cast<const bf16x8*>(base + ((((size_t)tile * nk + s) * 2 + part) * 64 + lane) * 8);
+}
+
+// LDS activation image: [col group][k-step][part][lane][8 bf16]  (1 KB blocks)
+__device__ __forceinline__ int act_off(int cg, int s, int part, int lane) {
+  return (((cg * NK_H + s) * 2 + part) * 64 + lane) * 16;   // bytes
+}
+
+template <bool SPLIT>
+__device__ __forceinline__ f32x4 mma3(const bf16x8 whi, const bf16x8 wlo, const bf16x8 ahi, const bf16x8 alo, f32x4 acc) {
+  // weights are the A operand (rows = output features), activations the B operand
+  if (SPLIT) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ahi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, alo, acc, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, ahi, acc, 0, 0, 0);
+}
+template <bool SPLIT>
+__device__ __forceinline__ f32x4 mma3_flip(const bf16x8 ahi, const bf16x8 alo, const bf16x8 whi, const bf16x8 wlo, f32x4 acc) {
+  // activations are the A operand (rows = samples), weights the B operand (cols = features)
+  if (SPLIT) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, wlo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, whi, acc, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, whi, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void split8(const float (&z)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __bf16 h = (__bf16)z[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(z[j] - (float)h);
+  }
+}
+
+// tanh + split + store one accumulator tile (feature tile `tile`) into the LDS image
+__device__ __forceinline__ void store_act(char* act, int cg, int tile, int lane, f32x4 acc) {
+  f32x4 h;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) h[t] = fast_tanh(acc[t]);
+  bf16x4 hi, lo;
+  split4(h, hi, lo);
+  const int s = tile >> 1, e = tile & 1;
+  *reinterpret_cast<bf16x4*>(act + act_off(cg, s, 0, lane) + e * 8) = hi;
+  *reinterpret_cast<bf16x4*>(act + act_off(cg, s, 1, lane) + e * 8) = lo;
+}
+
+// Hidden layers 1 and 2 for NCG column groups.  zhi/zlo: layer-1 B fragments (the
+// latent rows); bias1[ti][cg]: accumulator init of layer 1 (per-column bias for M2).
+// Leaves tanh(layer 2) in act2 (LDS, fragment order).  Two workgroup barriers.
+template <int NW, int NCG, bool SPLIT>
+__device__ __forceinline__ void hidden_layers(const DecW& dw, char* act1, char* act2, int w, int lane,
+                                              const bf16x8 (&zhi)[NCG], const bf16x8 (&zlo)[NCG],
+                                              const f32x4 (&bias1)[NT_H / NW][NCG], const f32x4 (&bias2)[NT_H / NW]) {
+  constexpr int TPW = NT_H / NW;
+  // ---- layer 1: K = LAT = 32 -> one k-step
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti) {
+    const int tile = w + NW * ti;
+    const bf16x8 whi = ldw(dw.w1f, tile, 1, 0, 0, lane);
+    const bf16x8 wlo = ldw(dw.w1f, tile, 1, 0, 1, lane);
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+      f32x4 acc = mma3<SPLIT>(whi, wlo, zhi[cg], zlo[cg], bias1[ti][cg]);
+      store_act(act1, cg, tile, lane, acc);
+    }
+  }
+  __syncthreads();
+  // ---- layer 2
+  f32x4 acc2[TPW][NCG];
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) acc2[ti][cg] = bias2[ti];
+#pragma unroll
+  for (int s = 0; s < NK_H; ++s) {
+    bf16x8 ahi[NCG], alo[NCG];
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+      ahi[cg] = *reinterpret_cast<const bf16x8*>(act1 + act_off(cg, s, 0, lane));
+      alo[cg] = *reinterpret_cast<const bf16x8*>(act1 + act_off(cg, s, 1, lane));
+    }
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+      const int tile = w + NW * ti;
+      const bf16x8 whi = ldw(dw.w2f, tile, NK_H, s, 0, lane);
+      const bf16x8 wlo = ldw(dw.w2f, tile, NK_H, s, 1, lane);
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) acc2[ti][cg] = mma3<SPLIT>(whi, wlo, ahi[cg], alo[cg], acc2[ti][cg]);
+    }
+  }
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) store_act(act2, cg, w + NW * ti, lane, acc2[ti][cg]);
+  __syncthreads();
+}
+
+// Last layer, orientation [features x columns]: acc[i][cg] rows = bins 16*tile+4q+t.
+template <int NW, int NCG, bool SPLIT>
+__device__ __forceinline__ void out_layer(const DecW& dw, const char* act2, int w, int lane, f32x4 (&acc)[MAXT][NCG]) {
+#pragma unroll
+  for (int s = 0; s < NK_H; ++s) {
+    bf16x8 ahi[NCG], alo[NCG];
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+      ahi[cg] = *reinterpret_cast<const bf16x8*>(act2 + act_off(cg, s, 0, lane));
+      alo[cg] = *reinterpret_cast<const bf16x8*>(act2 + act_off(cg, s, 1, lane));
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int tile = w + NW * i;
+      if (tile < dw.NT3) {   // wave-uniform
+        const bf16x8 whi = ldw(dw.w3f, tile, NK_H, s, 0, lane);
+        const bf16x8 wlo = ldw(dw.w3f, tile, NK_H, s, 1, lane);
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg) acc[i][cg] = mma3<SPLIT>(whi, wlo, ahi[cg], alo[cg], acc[i][cg]);
+      }
+    }
+  }
+}
+// Last layer, orientation [columns x features]: acc[i][cg] rows = samples 4q+t, col = bin 16*tile+c.
+template <int NW, int NCG, bool SPLIT>
+__device__ __forceinline__ void out_layer_flip(const DecW& dw, const char* act2, int w, int lane, f32x4 (&acc)[MAXT][NCG]) {
+#pragma unroll
+  for (int s = 0; s < NK_H; ++s) {
+    bf16x8 ahi[NCG], alo[NCG];
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+      ahi[cg] = *reinterpret_cast<const bf16x8*>(act2 + act_off(cg, s, 0, lane));
+      alo[cg] = *reinterpret_cast<const bf16x8*>(act2 + act_off(cg, s, 1, lane));
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int tile = w + NW * i;
+      if (tile < dw.NT3) {
+        const bf16x8 whi = ldw(dw.w3f, tile, NK_H, s, 0, lane);
+        const bf16x8 wlo = ldw(dw.w3f, tile, NK_H, s, 1, lane);
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg) acc[i][cg] = mma3_flip<SPLIT>(ahi[cg], alo[cg], whi, wlo, acc[i][cg]);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
+
+// ============================================================================
+// MH chain (mcem.py:371-441 / :218-294)
+// ============================================================================
+struct ChainArgs {
+  DecW dw;
+  const float *X2, *W, *Ht, *g, *B1;
+  float *Z, *Zs, *acc_out;
+  const int32_t *tile_utt, *tile_n0, *tile_cnt, *frame_off;
+  const uint64_t* utt_seed;
+  const float *eps, *u;      // replay buffers or null
+  int Fs, Kp, NT, Rcap, nsamples, burnin, rng_mode;
+  uint32_t call;
+  float sd;                  // sqrt(var_RW)
+};
+
+constexpr int ACT_BYTES_CHAIN = 2 * NK_H * 2 * 1024;   // 2 column groups
+
+struct ChainLds {
+  char act1[ACT_BYTES_CHAIN];
+  char act2[ACT_BYTES_CHAIN];
+  float eps[2][FRAMES_PER_TILE][LAT];
+  float u[2][FRAMES_PER_TILE];
+  double epart[2][8][FRAMES_PER_TILE];
+};
+
+template <int NW, bool SPLIT>
+__global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ChainLds& L = *reinterpret_cast<ChainLds*>(smem);
+  constexpr int TPW = NT_H / NW;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4, c = lane & 15;
+  const int tile = blockIdx.x;
+  const int utt = a.tile_utt[tile], n0 = a.tile_n0[tile], cnt = a.tile_cnt[tile];
+  const DecW& dw = a.dw;
+
+  // ---- frames of this lane (one per column group)
+  int nrow[2];
+  bool fvalid[2];
+  float gn[2];
+#pragma unroll
+  for (int fg = 0; fg < 2; ++fg) {
+    const int j = 16 * fg + c;
+    fvalid[fg] = j < cnt;
+    nrow[fg] = n0 + (j < cnt ? j : cnt - 1);
+    gn[fg] = a.g[nrow[fg]];
+  }
+  // ---- per-(bin,frame) constants in accumulator layout: X2 and Vb = W H (mcem.py:81-82)
+  f32x4 x2[MAXT][2], vb[MAXT][2], b3v[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int t16 = w + NW * i;
+    const int f0 = 16 * t16 + 4 * q;
+    const bool tv = t16 < dw.NT3;
+    b3v[i] = tv ? *reinterpret_cast<const f32x4*>(dw.b3 + f0) : f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int fg = 0; fg < 2; ++fg) {
+      x2[i][fg] = tv ? *reinterpret_cast<const f32x4*>(a.X2 + (size_t)nrow[fg] * a.Fs + f0) : f32x4{0, 0, 0, 0};
+      f32x4 v = {0, 0, 0, 0};
+      if (tv) {
+        for (int k = 0; k < a.Kp; k += 4) {
+          const f32x4 h = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)nrow[fg] * a.Kp + k);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const f32x4 wr = *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + f0 + t) * a.Kp + k);
+            v[t] += wr[0] * h[0] + wr[1] * h[1] + wr[2] * h[2] + wr[3] * h[3];
+          }
+        }
+      }
+      vb[i][fg] = v;
+    }
+  }
+  // ---- layer biases
+  f32x4 bias1[TPW][2], bias2[TPW];
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti) {
+    const int f0 = 16 * (w + NW * ti) + 4 * q;
+    bias2[ti] = *reinterpret_cast<const f32x4*>(dw.b2 + f0);
+#pragma unroll
+    for (int fg = 0; fg < 2; ++fg)
+      bias1[ti][fg] = a.B1 ? *reinterpret_cast<const f32x4*>(a.B1 + (size_t)nrow[fg] * HID + f0)
+                           : *reinterpret_cast<const f32x4*>(dw.b1 + f0);
+  }
+  // ---- current latent state, fragment order: latents 4q..4q+3 and 16+4q..16+4q+3
+  float z[2][8];
+#pragma unroll
+  for (int fg = 0; fg < 2; ++fg) {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(a.Z + (size_t)nrow[fg] * LAT + 4 * q);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(a.Z + (size_t)nrow[fg] * LAT + 16 + 4 * q);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { z[fg][t] = lo[t]; z[fg][4 + t] = hi[t]; }
+  }
+  // ---- noise streams: thread id <-> (frame of the tile, latent quad); 256 streams
+  const int sid = threadIdx.x, sfr = sid >> 3, squad = sid & 7;
+  const bool srng = sid < FRAMES_PER_TILE * 8;
+  const bool sval = srng && sfr < cnt;
+  Xs128 st;
+  if (sval && a.rng_mode == VAENMF_RNG_DEVICE)
+    st = xs_seed(a.utt_seed[utt], (uint32_t)(n0 - a.frame_off[utt] + sfr), (uint32_t)squad, a.call);
+  auto draw = [&](int step) {   // noise of MH step `step` -> LDS buffer step&1
+    if (!srng) return;
+    f32x4 e = {0, 0, 0, 0};
+    float uu = 0.5f;
+    if (sval) {
+      if (a.rng_mode == VAENMF_RNG_DEVICE) {
+        e = normal4(st);
+        if (squad == 0) uu = uniform01(st);
+      } else {
+        const size_t row = (size_t)step * a.NT + n0 + sfr;
+        e = *reinterpret_cast<const f32x4*>(a.eps + row * LAT + 4 * squad);
+        if (squad == 0) uu = a.u[row];
+      }
+    }
+    *reinterpret_cast<f32x4*>(&L.eps[step & 1][sfr][4 * squad]) = e;
+    if (squad == 0) L.u[step & 1][sfr] = uu;
+  };
+
+  int ecount = 0;
+  // E(z) = sum_f [log Vx + X2/Vx] per frame (fp64 accumulation: the reference sums the
+  // per-bin DIFFERENCES of two states, mcem.py:415-416; summing each state separately
+  // needs the extra bits to keep the same absolute accuracy).
+  auto energy = [&](const float (&zz)[2][8], double (&E)[2]) {
+    bf16x8 zhi[2], zlo[2];
+    split8(zz[0], zhi[0], zlo[0]);
+    split8(zz[1], zhi[1], zlo[1]);
+    hidden_layers<NW, 2, SPLIT>(dw, L.act1, L.act2, w, lane, zhi, zlo, bias1, bias2);
+    f32x4 acc[MAXT][2];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) { acc[i][0] = b3v[i]; acc[i][1] = b3v[i]; }
+    out_layer<NW, 2, SPLIT>(dw, L.act2, w, lane, acc);
+    double e[2] = {0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int t16 = w + NW * i;
+      if (t16 < dw.NT3) {
+#pragma unroll
+        for (int fg = 0; fg < 2; ++fg) {
+          float part = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float vs = fast_exp(acc[i][fg][t]);
+            const float vx = gn[fg] * vs + vb[i][fg][t];
+            const float term = fast_log(vx) + x2[i][fg][t] * fast_rcp(vx);
+            part += (16 * t16 + 4 * q + t < dw.F) ? term : 0.f;
+          }
+          e[fg] += (double)part;
+        }
+      }
+    }
+    const int par = ecount & 1;
+    ++ecount;
+#pragma unroll
+    for (int fg = 0; fg < 2; ++fg) {
+      e[fg] += shfl_xor_d(e[fg], 16);
+      e[fg] += shfl_xor_d(e[fg], 32);
+      if (q == 0) L.epart[par][w][16 * fg + c] = e[fg];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int fg = 0; fg < 2; ++fg) {
+      double s = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) s += L.epart[par][ww][16 * fg + c];
+      E[fg] = s;
+    }
+  };
+
+  const int S = a.nsamples + a.burnin;
+  draw(0);
+  double Ecur[2];
+  energy(z, Ecur);                                    // Vs_t = decoder(Z_t)  (mcem.py:392-400)
+  for (int m = 0; m < S; ++m) {
+    // ---- proposal  Z' = Z + sqrt(var) * randn   (mcem.py:407)
+    float zp[2][8];
+#pragma unroll
+    for (int fg = 0; fg < 2; ++fg) {
+      const f32x4 e0 = *reinterpret_cast<const f32x4*>(&L.eps[m & 1][16 * fg + c][4 * q]);
+      const f32x4 e1 = *reinterpret_cast<const f32x4*>(&L.eps[m & 1][16 * fg + c][16 + 4 * q]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        zp[fg][t] = z[fg][t] + a.sd * e0[t];
+        zp[fg][4 + t] = z[fg][4 + t] + a.sd * e1[t];
+      }
+    }
+    if (m + 1 < S) draw(m + 1);
+    double Ep[2];
+    energy(zp, Ep);                                   // mcem.py:410-412
+#pragma unroll
+    for (int fg = 0; fg < 2; ++fg) {
+      float pr = 0.f;                                 // .5*sum(Z^2 - Z'^2)  (mcem.py:417)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pr += z[fg][j] * z[fg][j] - zp[fg][j] * zp[fg][j];
+      pr += __shfl_xor(pr, 16, 64);
+      pr += __shfl_xor(pr, 32, 64);
+      const float accp = (float)(Ecur[fg] - Ep[fg]) + 0.5f * pr;
+      const float uu = L.u[m & 1][16 * fg + c];
+      const bool ok = logf(uu) < accp;                // mcem.py:420
+      if (a.acc_out && w == 0 && q == 0 && fvalid[fg]) a.acc_out[(size_t)m * a.NT + nrow[fg]] = accp;
+      if (ok) {                                       // mcem.py:429-433
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[fg][j] = zp[fg][j];
+        Ecur[fg] = Ep[fg];
+      }
+      if (m >= a.burnin && w == 0 && fvalid[fg]) {    // mcem.py:435-437
+        float* dst = a.Zs + ((size_t)nrow[fg] * a.Rcap + (m - a.burnin)) * LAT;
+        *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{z[fg][0], z[fg][1], z[fg][2], z[fg][3]};
+        *reinterpret_cast<f32x4*>(dst + 16 + 4 * q) = f32x4{z[fg][4], z[fg][5], z[fg][6], z[fg][7]};
+      }
+    }
+  }
+  if (w == 0) {                                       // self.Z = last draw (mcem.py:466)
+#pragma unroll
+    for (int fg = 0; fg < 2; ++fg)
+      if (fvalid[fg]) {
+        float* dst = a.Z + (size_t)nrow[fg] * LAT;
+        *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{z[fg][0], z[fg][1], z[fg][2], z[fg][3]};
+        *reinterpret_cast<f32x4*>(dst + 16 + 4 * q) = f32x4{z[fg][4], z[fg][5], z[fg][6], z[fg][7]};
+      }
+  }
+}
+
+// same streams as mh_chain_kernel::draw, written to global memory (test aid)
+__global__ void rng_fill_kernel(const int32_t* tile_utt, const int32_t* tile_n0, const int32_t* tile_cnt,
+                                const int32_t* frame_off, const uint64_t* utt_seed, uint32_t call, int S, int NT,
+                                float* eps_out, float* u_out) {
+  const int tile = blockIdx.x, sid = threadIdx.x, sfr = sid >> 3, squad = sid & 7;
+  const int utt = tile_utt[tile], n0 = tile_n0[tile], cnt = tile_cnt[tile];
+  if (sfr >= cnt) return;
+  Xs128 st = xs_seed(utt_seed[utt], (uint32_t)(n0 - frame_off[utt] + sfr), (uint32_t)squad, call);
+  for (int s = 0; s < S; ++s) {
+    const f32x4 e = normal4(st);
+    const size_t row = (size_t)s * NT + n0 + sfr;
+    *reinterpret_cast<f32x4*>(eps_out + row * LAT + 4 * squad) = e;
+    if (squad == 0) u_out[row] = uniform01(st);
+  }
+}
+
+// ============================================================================
+// Sample decode + fused epilogues (compute_Vs mcem.py:444-454, M_step :90-152,
+// cost :68-70, compute_WF :486-488)
+// ============================================================================
+enum { MODE_STORE = 0, MODE_WSTATS = 1, MODE_HG = 2, MODE_WF = 3 };
+
+struct DecodeArgs {
+  DecW dw;
+  const float *X2, *W, *B1, *Zs, *normW, *X;
+  float *Ht, *g;                       // read (and written by MODE_HG)
+  float *Vs_out, *A1, *P, *S_hat, *N_hat, *WFs, *WFn;
+  double* cost_frames;
+  const int32_t* frame_utt;
+  int Fs, K, NT, Rcap, R;
+};
+
+constexpr int ACT_BYTES_DEC = 2 * NK_H * 2 * 1024;   // 2 sample groups of 16
+
+struct DecodeLds {
+  char act1[ACT_BYTES_DEC];
+  char act2[ACT_BYTES_DEC];
+  float redH[8][64];        // [wave][2*Kp]
+  float redG[8][2];
+  double redC[8];
+};
+
+template <int NW, bool SPLIT, int MODE, int KP>
+__global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DecodeLds& L = *reinterpret_cast<DecodeLds*>(smem);
+  constexpr int TPW = NT_H / NW;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4, c = lane & 15;
+  const DecW& dw = a.dw;
+  constexpr int Kp = KP;
+  const int nch = (a.R + 31) / 32;
+
+  f32x4 bias2[TPW];
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti) bias2[ti] = *reinterpret_cast<const f32x4*>(dw.b2 + 16 * (w + NW * ti) + 4 * q);
+  float b3c[MAXT];
+  int fidx[MAXT];
+  bool fval[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int t16 = w + NW * i;
+    fidx[i] = 16 * t16 + c;
+    fval[i] = t16 < dw.NT3 && fidx[i] < dw.F;
+    b3c[i] = (t16 < dw.NT3) ? dw.b3[fidx[i]] : 0.f;
+  }
+
+  for (int n = blockIdx.x; n < a.NT; n += gridDim.x) {
+    const int utt = a.frame_utt[n];
+    f32x4 bias1[TPW][2];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+      const int f0 = 16 * (w + NW * ti) + 4 * q;
+      bias1[ti][0] = a.B1 ? *reinterpret_cast<const f32x4*>(a.B1 + (size_t)n * HID + f0)
+                          : *reinterpret_cast<const f32x4*>(dw.b1 + f0);
+      bias1[ti][1] = bias1[ti][0];
+    }
+    // decode 32 samples (chunk ch) of frame n: vs[i][sg][t] = Vs(sample 32ch+16sg+4q+t, bin fidx[i])
+    auto decode_chunk = [&](int ch, f32x4 (&vs)[MAXT][2]) {
+      bf16x8 zhi[2], zlo[2];
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg) {
+        int r = 32 * ch + 16 * sg + c;
+        r = r < a.R ? r : a.R - 1;
+        const float* src = a.Zs + ((size_t)n * a.Rcap + r) * LAT;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(src + 4 * q);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 16 + 4 * q);
+        const float zz[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        split8(zz, zhi[sg], zlo[sg]);
+      }
+      hidden_layers<NW, 2, SPLIT>(dw, L.act1, L.act2, w, lane, zhi, zlo, bias1, bias2);
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) { vs[i][0] = f32x4{b3c[i], b3c[i], b3c[i], b3c[i]}; vs[i][1] = vs[i][0]; }
+      out_layer_flip<NW, 2, SPLIT>(dw, L.act2, w, lane, vs);
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i)
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) vs[i][sg][t] = fast_exp(vs[i][sg][t]);
+    };
+    auto rvalid = [&](int ch, int sg, int t) { return 32 * ch + 16 * sg + 4 * q + t < a.R; };
+    auto sum_q = [&](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
+    auto sum_c = [&](float v) {
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      return v;
+    };
+
+    if (MODE == MODE_STORE) {
+      for (int ch = 0; ch < nch; ++ch) {
+        f32x4 vs[MAXT][2];
+        decode_chunk(ch, vs);
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i)
+          if (w + NW * i < dw.NT3)
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                if (rvalid(ch, sg, t))
+                  a.Vs_out[((size_t)n * a.R + 32 * ch + 16 * sg + 4 * q + t) * a.Fs + fidx[i]] = fval[i] ? vs[i][sg][t] : 0.f;
+      }
+      continue;
+    }
+
+    // ---- per-bin constants of frame n: X2, Vb = sum_k W[f,k] H[k,n]
+    const float gn = a.g[n];
+    float x2f[MAXT], vb[MAXT];
+    auto dotWH = [&](int i, const float (&hvec)[KP]) {   // sum_k W[utt][fidx][k] * hvec[k]
+      float v = 0.f;
+      const float* wr = a.W + ((size_t)utt * a.Fs + fidx[i]) * Kp;
+#pragma unroll
+      for (int k = 0; k < Kp; k += 4) {
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(wr + k);
+        v += ww[0] * hvec[k] + ww[1] * hvec[k + 1] + ww[2] * hvec[k + 2] + ww[3] * hvec[k + 3];
+      }
+      return v;
+    };
+    float hs[KP];   // H[:,n] (MODE_HG: times the pending column norms of W)
+#pragma unroll
+    for (int k = 0; k < Kp; ++k) hs[k] = a.Ht[(size_t)n * Kp + k] * (MODE == MODE_HG ? a.normW[(size_t)utt * Kp + k] : 1.f);
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const bool tv = w + NW * i < dw.NT3;
+      x2f[i] = tv ? a.X2[(size_t)n * a.Fs + fidx[i]] : 0.f;
+      vb[i] = tv ? dotWH(i, hs) : 1.f;
+    }
+
+    if (MODE == MODE_WSTATS) {
+      // A1 = sum_r 1/Vx, A2 = sum_r 1/Vx^2 with the pre-update variances (mcem.py:107-109)
+      float a1[MAXT], a2[MAXT];
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) a1[i] = a2[i] = 0.f;
+      for (int ch = 0; ch < nch; ++ch) {
+        f32x4 vs[MAXT][2];
+        decode_chunk(ch, vs);
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float r = rvalid(ch, sg, t) ? fast_rcp(gn * vs[i][sg][t] + vb[i]) : 0.f;
+              a1[i] += r;
+              a2[i] += r * r;
+            }
+      }
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) {
+        const float s1 = sum_q(a1[i]), s2 = sum_q(a2[i]);
+        if (q == 0 && w + NW * i < dw.NT3) {
+          a.A1[(size_t)n * a.Fs + fidx[i]] = fval[i] ? s1 : 0.f;
+          a.P[(size_t)n * a.Fs + fidx[i]] = fval[i] ? x2f[i] * s2 : 0.f;
+        }
+      }
+    } else if (MODE == MODE_WF) {
+      // WFs = mean_r(g Vs / Vx), WFn = mean_r(Vb / Vx)  (mcem.py:486-488)
+      float ws[MAXT], wn[MAXT];
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) ws[i] = wn[i] = 0.f;
+      for (int ch = 0; ch < nch; ++ch) {
+        f32x4 vs[MAXT][2];
+        decode_chunk(ch, vs);
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (rvalid(ch, sg, t)) {
+                const float sc = gn * vs[i][sg][t];
+                const float r = fast_rcp(sc + vb[i]);
+                ws[i] += sc * r;
+                wn[i] += vb[i] * r;
+              }
+      }
+      const float invR = 1.0f / (float)a.R;
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) {
+        const float s = sum_q(ws[i]) * invR, nn = sum_q(wn[i]) * invR;
+        if (q == 0 && w + NW * i < dw.NT3) {
+          const size_t o = (size_t)n * a.Fs + fidx[i];
+          const float xr = a.X[2 * o], xi = a.X[2 * o + 1];
+          a.S_hat[2 * o] = fval[i] ? s * xr : 0.f;  a.S_hat[2 * o + 1] = fval[i] ? s * xi : 0.f;   // mcem.py:175
+          a.N_hat[2 * o] = fval[i] ? nn * xr : 0.f; a.N_hat[2 * o + 1] = fval[i] ? nn * xi : 0.f;  // mcem.py:176
+          if (a.WFs) a.WFs[o] = fval[i] ? s : 0.f;
+          if (a.WFn) a.WFn[o] = fval[i] ? nn : 0.f;
+        }
+      }
+    } else if (MODE == MODE_HG) {
+      f32x4 vs[MAXT][2];
+      // ---- H update (mcem.py:118-121): W already updated + normalised by w_update_kernel
+      float a1[MAXT], a2[MAXT];
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) a1[i] = a2[i] = 0.f;
+      for (int ch = 0; ch < nch; ++ch) {
+        decode_chunk(ch, vs);
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float r = rvalid(ch, sg, t) ? fast_rcp(gn * vs[i][sg][t] + vb[i]) : 0.f;
+              a1[i] += r;
+              a2[i] += r * r;
+            }
+      }
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) {
+        const float s1 = sum_q(a1[i]), s2 = sum_q(a2[i]);
+        a1[i] = fval[i] ? s1 : 0.f;
+        a2[i] = fval[i] ? s2 * x2f[i] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < Kp; ++k) {
+        float nu = 0.f, de = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i)
+          if (fval[i]) {
+            const float wk = a.W[((size_t)utt * a.Fs + fidx[i]) * Kp + k];
+            nu += wk * a2[i];
+            de += wk * a1[i];
+          }
+        nu = sum_c(nu);
+        de = sum_c(de);
+        if (lane == 0) { L.redH[w][2 * k] = nu; L.redH[w][2 * k + 1] = de; }
+      }
+      __syncthreads();
+      float hn[KP];
+#pragma unroll
+      for (int k = 0; k < Kp; ++k) {
+        float nu = 0.f, de = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) { nu += L.redH[ww][2 * k]; de += L.redH[ww][2 * k + 1]; }
+        hn[k] = (k < a.K) ? hs[k] * sqrtf(nu / de) : 0.f;
+      }
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < Kp; k += 4)
+          *reinterpret_cast<f32x4*>(a.Ht + (size_t)n * Kp + k) = f32x4{hn[k], hn[k + 1], hn[k + 2], hn[k + 3]};
+      }
+      // ---- variances with the new W, H (mcem.py:124-125), then g update (mcem.py:138-142)
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) vb[i] = (w + NW * i < dw.NT3) ? dotWH(i, hn) : 1.f;
+      float ng[MAXT], dg[MAXT];
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) ng[i] = dg[i] = 0.f;
+      for (int ch = 0; ch < nch; ++ch) {
+        if (nch > 1) decode_chunk(ch, vs);
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (rvalid(ch, sg, t)) {
+                const float v = vs[i][sg][t];
+                const float r = fast_rcp(gn * v + vb[i]);
+                ng[i] += v * r * r;
+                dg[i] += v * r;
+              }
+      }
+      float nu = 0.f, de = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) {
+        const float sn = sum_q(ng[i]), sdn = sum_q(dg[i]);
+        if (fval[i]) { nu += x2f[i] * sn; de += sdn; }
+      }
+      nu = sum_c(nu);
+      de = sum_c(de);
+      if (lane == 0) { L.redG[w][0] = nu; L.redG[w][1] = de; }
+      __syncthreads();
+      nu = de = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) { nu += L.redG[ww][0]; de += L.redG[ww][1]; }
+      const float gnew = gn * sqrtf(nu / de);
+      if (threadIdx.x == 0) a.g[n] = gnew;
+      // ---- cost (mcem.py:70) with the refreshed variances (mcem.py:151-152)
+      float cs = 0.f;
+      for (int ch = 0; ch < nch; ++ch) {
+        if (nch > 1) decode_chunk(ch, vs);
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i)
+          if (fval[i])
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                if (rvalid(ch, sg, t)) {
+                  const float vx = gnew * vs[i][sg][t] + vb[i];
+                  cs += fast_log(vx) + x2f[i] * fast_rcp(vx);
+                }
+      }
+      double cd = (double)cs;
+      cd += shfl_xor_d(cd, 1); cd += shfl_xor_d(cd, 2); cd += shfl_xor_d(cd, 4); cd += shfl_xor_d(cd, 8);
+      cd += shfl_xor_d(cd, 16); cd += shfl_xor_d(cd, 32);
+      if (lane == 0) L.redC[w] = cd;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int ww = 0; ww < NW; ++ww) s += L.redC[ww];
+        a.cost_frames[n] = s;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// ============================================================================
+// Host launchers (C ABI)
+// ============================================================================
+namespace {
+
+DecW make_decw(const vaenmf_plan* p) {
+  DecW d;
+  d.w1f = p->w1f; d.w2f = p->w2f; d.w3f = p->w3f;
+  d.b1 = p->b1; d.b2 = p->b2; d.b3 = p->b3;
+  d.NT3 = p->NT3; d.F = p->cfg.F;
+  return d;
+}
+
+template <int NW, bool SPLIT>
+int launch_chain(const ChainArgs& a, int n_tiles, hipStream_t st) {
+  hipLaunchKernelGGL((mh_chain_kernel<NW, SPLIT>), dim3(n_tiles), dim3(NW * 64), sizeof(ChainLds), st, a);
+  return 0;
+}
+
+template <int NW, bool SPLIT, int MODE>
+int launch_decode_kp(const DecodeArgs& a, int Kp, int grid, hipStream_t st) {
+  const size_t lds = sizeof(DecodeLds);
+  switch (Kp) {
+    case 8:  hipLaunchKernelGGL((decode_kernel<NW, SPLIT, MODE, 8>), dim3(grid), dim3(NW * 64), lds, st, a); break;
+    case 16: hipLaunchKernelGGL((decode_kernel<NW, SPLIT, MODE, 16>), dim3(grid), dim3(NW * 64), lds, st, a); break;
+    default: hipLaunchKernelGGL((decode_kernel<NW, SPLIT, MODE, 32>), dim3(grid), dim3(NW * 64), lds, st, a); break;
+  }
+  return 0;
+}
+template <int MODE>
+int launch_decode(const vaenmf_plan* p, const DecodeArgs& a, hipStream_t st) {
+  const int grid = a.NT < p->n_sms * 8 ? a.NT : p->n_sms * 8;
+  const bool split = p->cfg.precision == VAENMF_PREC_BF16X3;
+  const int Kp = (MODE == MODE_STORE) ? 8 : p->Kp;
+  if (p->nwaves == 4) return split ? launch_decode_kp<4, true, MODE>(a, Kp, grid, st) : launch_decode_kp<4, false, MODE>(a, Kp, grid, st);
+  return split ? launch_decode_kp<8, true, MODE>(a, Kp, grid, st) : launch_decode_kp<8, false, MODE>(a, Kp, grid, st);
+}
+
+DecodeArgs base_decode_args(const vaenmf_plan* p, const float* Zs, int Rcap, int R, const float* B1) {
+  DecodeArgs a = {};
+  a.dw = make_decw(p);
+  a.Zs = Zs; a.B1 = B1; a.frame_utt = p->d_frame_utt;
+  a.Fs = p->Fs; a.K = p->cfg.K; a.NT = p->NT; a.Rcap = Rcap; a.R = R;
+  return a;
+}
+
+int check_bound(const vaenmf_plan* p) {
+  VN_REQUIRE(p != nullptr, "null plan");
+  VN_REQUIRE(p->have_weights, "decoder weights not set (vaenmf_set_decoder_weights)");
+  VN_REQUIRE(p->NT > 0, "no batch bound (vaenmf_bind_batch)");
+  return 0;
+}
+
+}  // namespace
+
+// aux.hip
+int vn_launch_w_update(const vaenmf_plan* p, float* W, const float* Ht, hipStream_t st);
+int vn_launch_cost_reduce(const vaenmf_plan* p, const double* cost_frames, int R, double* cost, int niter, int it, hipStream_t st);
+
+extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, const float* Ht, const float* g,
+                               float* Z, const float* B1, float* Zs, int32_t Rcap, int32_t nsamples, int32_t burnin,
+                               float var_rw, const vaenmf_rng* rng, float* acc_out, void* stream) {
+  if (int e = check_bound(p)) return e;
+  VN_REQUIRE(rng != nullptr, "rng is null");
+  VN_REQUIRE(nsamples >= 1 && burnin >= 0 && nsamples <= Rcap, "bad sample counts (nsamples=%d burnin=%d Rcap=%d)", nsamples, burnin, Rcap);
+  VN_REQUIRE(rng->mode == VAENMF_RNG_DEVICE || (rng->eps && rng->u), "replay mode needs eps and u buffers");
+  ChainArgs a = {};
+  a.dw = make_decw(p);
+  a.X2 = X2; a.W = W; a.Ht = Ht; a.g = g; a.B1 = B1; a.Z = Z; a.Zs = Zs; a.acc_out = acc_out;
+  a.tile_utt = p->d_tile_utt; a.tile_n0 = p->d_tile_n0; a.tile_cnt = p->d_tile_cnt; a.frame_off = p->d_frame_off;
+  a.utt_seed = p->d_utt_seed; a.eps = rng->eps; a.u = rng->u;
+  a.Fs = p->Fs; a.Kp = p->Kp; a.NT = p->NT; a.Rcap = Rcap; a.nsamples = nsamples; a.burnin = burnin;
+  a.rng_mode = rng->mode; a.call = rng->call; a.sd = sqrtf(var_rw);
+  hipStream_t st = (hipStream_t)stream;
+  const bool split = p->cfg.precision == VAENMF_PREC_BF16X3;
+  if (p->nwaves == 4) { if (split) launch_chain<4, true>(a, p->n_tiles, st); else launch_chain<4, false>(a, p->n_tiles, st); }
+  else                { if (split) launch_chain<8, true>(a, p->n_tiles, st); else launch_chain<8, false>(a, p->n_tiles, st); }
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vaenmf_rng_fill(vaenmf_plan* p, uint32_t call, int32_t S, float* eps_out, float* u_out, void* stream) {
+  if (int e = check_bound(p)) return e;
+  hipLaunchKernelGGL(rng_fill_kernel, dim3(p->n_tiles), dim3(256), 0, (hipStream_t)stream, p->d_tile_utt, p->d_tile_n0,
+                     p->d_tile_cnt, p->d_frame_off, p->d_utt_seed, call, S, p->NT, eps_out, u_out);
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vaenmf_decode(vaenmf_plan* p, const float* Zs, int32_t Rcap, int32_t R, const float* B1, float* Vs_out, void* stream) {
+  if (int e = check_bound(p)) return e;
+  VN_REQUIRE(R >= 1 && R <= Rcap, "bad R=%d (Rcap=%d)", R, Rcap);
+  DecodeArgs a = base_decode_args(p, Zs, Rcap, R, B1);
+  a.Vs_out = Vs_out;
+  launch_decode<MODE_STORE>(p, a, (hipStream_t)stream);
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vaenmf_m_step(vaenmf_plan* p, const float* X2, float* W, float* Ht, float* g, const float* Zs,
+                             int32_t Rcap, int32_t R, const float* B1, double* cost_frames, void* stream) {
+  if (int e = check_bound(p)) return e;
+  VN_REQUIRE(R >= 1 && R <= Rcap, "bad R=%d (Rcap=%d)", R, Rcap);
+  hipStream_t st = (hipStream_t)stream;
+  DecodeArgs a = base_decode_args(p, Zs, Rcap, R, B1);
+  a.X2 = X2; a.W = W; a.Ht = Ht; a.g = g; a.A1 = p->A1; a.P = p->P; a.normW = p->normW;
+  a.cost_frames = cost_frames ? cost_frames : p->cost_frames;
+  launch_decode<MODE_WSTATS>(p, a, st);                 // A1, X2*A2 per (frame, bin)
+  if (int e = vn_launch_w_update(p, W, Ht, st)) return e;  // W <- W sqrt(num/den), L1 column norms
+  launch_decode<MODE_HG>(p, a, st);                     // H, g, cost
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vaenmf_wiener(vaenmf_plan* p, const float* X2, const float* W, const float* Ht, const float* g,
+                             const float* Zs, int32_t Rcap, int32_t R, const float* B1, const float* X,
+                             float* S_hat, float* N_hat, float* WFs, float* WFn, void* stream) {
+  if (int e = check_bound(p)) return e;
+  VN_REQUIRE(R >= 1 && R <= Rcap, "bad R=%d (Rcap=%d)", R, Rcap);
+  DecodeArgs a = base_decode_args(p, Zs, Rcap, R, B1);
+  a.X2 = X2; a.W = W; a.Ht = const_cast<float*>(Ht); a.g = const_cast<float*>(g); a.X = X;
+  a.S_hat = S_hat; a.N_hat = N_hat; a.WFs = WFs; a.WFn = WFn;
+  launch_decode<MODE_WF>(p, a, (hipStream_t)stream);
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* Ht, float* g, float* Z, const float* B1,
+                             float* Zs, int32_t Rcap, int32_t niter, int32_t nsE, int32_t biE, int32_t nsWF, int32_t biWF,
+                             float var_rw, const float* X, float* S_hat, float* N_hat, double* cost, void* stream) {
+  if (int e = check_bound(p)) return e;
+  VN_REQUIRE(nsE <= Rcap && nsWF <= Rcap, "Rcap=%d too small for nsE=%d / nsWF=%d", Rcap, nsE, nsWF);
+  hipStream_t st = (hipStream_t)stream;
+  vaenmf_rng rng = {VAENMF_RNG_DEVICE, 0, nullptr, nullptr};
+  for (int it = 0; it < niter; ++it) {                  // EM.run, mcem.py:159-165
+    rng.call = (uint32_t)it;
+    if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, B1, Zs, Rcap, nsE, biE, var_rw, &rng, nullptr, stream)) return e;
+    if (int e = vaenmf_m_step(p, X2, W, Ht, g, Zs, Rcap, nsE, B1, p->cost_frames, stream)) return e;
+    if (cost) if (int e = vn_launch_cost_reduce(p, p->cost_frames, nsE, cost, niter, it, st)) return e;
+  }
+  rng.call = (uint32_t)niter;                           // compute_WF(sample=True), mcem.py:173
+  if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, B1, Zs, Rcap, nsWF, biWF, var_rw, &rng, nullptr, stream)) return e;
+  return vaenmf_wiener(p, X2, W, Ht, g, Zs, Rcap, nsWF, B1, X, S_hat, N_hat, nullptr, nullptr, stream);
+}

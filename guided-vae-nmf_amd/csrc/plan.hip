@@ -1,0 +1,213 @@
+// Plan management: shapes, device-resident decoder weights in MFMA fragment order,
+// batch tiling tables, workspace.  All allocation happens here.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void vaenmf_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* vaenmf_last_error(void) { return g_err; }
+
+namespace {
+
+uint16_t bf16_rne(float v) {                 // round-to-nearest-even, NaN kept quiet
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+float bf16_to_f(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float v;
+  memcpy(&v, &u, 4);
+  return v;
+}
+
+// W [out][ldw] (first `in` columns used) -> fragments [tile][kstep][part][lane][8]:
+// lane (q = lane>>4, i = lane&15), element j  <->  W[16 tile + i][32 s + 16 (j>>2) + 4 q + (j&3)]
+std::vector<uint16_t> pack_weights(const float* W, int out, int in, int ldw, int ntiles, int nk) {
+  std::vector<uint16_t> f((size_t)ntiles * nk * 2 * 64 * 8, 0);
+  for (int t = 0; t < ntiles; ++t)
+    for (int s = 0; s < nk; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int q = lane >> 4, i = lane & 15;
+        for (int j = 0; j < 8; ++j) {
+          const int row = 16 * t + i, col = 32 * s + 16 * (j >> 2) + 4 * q + (j & 3);
+          const float v = (row < out && col < in) ? W[(size_t)row * ldw + col] : 0.f;
+          const uint16_t hi = bf16_rne(v);
+          const uint16_t lo = bf16_rne(v - bf16_to_f(hi));
+          const size_t base = ((((size_t)t * nk + s) * 2) * 64 + lane) * 8 + j;
+          f[base] = hi;
+          f[base + 64 * 8] = lo;
+        }
+      }
+  return f;
+}
+
+template <typename T>
+int dev_alloc(T** p, size_t n) {
+  VN_CHECK_HIP(hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));
+  return 0;
+}
+template <typename T>
+int upload(T* dst, const T* src, size_t n) {
+  VN_CHECK_HIP(hipMemcpy(dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
+  VN_REQUIRE(cfg && out, "null argument");
+  VN_REQUIRE(cfg->L == LAT, "this build supports latent dim %d (got %d)", LAT, cfg->L);
+  VN_REQUIRE(cfg->H1 == HID && cfg->H2 == HID, "this build supports hidden sizes %d,%d (got %d,%d)", HID, HID, cfg->H1, cfg->H2);
+  VN_REQUIRE(cfg->F >= 1 && cfg->F <= 16 * MAXT * 8, "F=%d out of range (1..%d)", cfg->F, 16 * MAXT * 8);
+  VN_REQUIRE(cfg->K >= 1 && cfg->K <= 32, "NMF rank K=%d out of range (1..32)", cfg->K);
+  VN_REQUIRE(cfg->max_frames >= 1 && cfg->max_utts >= 1, "bad capacities");
+  VN_REQUIRE(cfg->precision == VAENMF_PREC_BF16X3 || cfg->precision == VAENMF_PREC_BF16, "bad precision");
+  vaenmf_plan* p = new vaenmf_plan();
+  memset((void*)&p->cfg, 0, sizeof(p->cfg));
+  p->cfg = *cfg;
+  p->Fs = (cfg->F + 15) / 16 * 16;
+  p->NT3 = p->Fs / 16;
+  p->Kp = cfg->K <= 8 ? 8 : (cfg->K <= 16 ? 16 : 32);
+  p->nwaves = p->NT3 <= 4 * MAXT ? 4 : 8;
+  p->w1f = p->w2f = p->w3f = nullptr;
+  p->b1 = p->b2 = p->b3 = p->w1y = nullptr;
+  p->Dy = 0;
+  p->have_weights = false;
+  p->n_utt = p->NT = p->n_tiles = 0;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  VN_CHECK_HIP(hipGetDevice(&dev));
+  VN_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+  p->n_sms = prop.multiProcessorCount;
+  const size_t NTc = cfg->max_frames, Uc = cfg->max_utts;
+  const size_t max_tiles = NTc / FRAMES_PER_TILE + Uc + 1;
+  int e = 0;
+  e |= dev_alloc(&p->w1f, (size_t)(HID / 16) * 1 * 2 * 64 * 8);
+  e |= dev_alloc(&p->w2f, (size_t)(HID / 16) * (HID / 32) * 2 * 64 * 8);
+  e |= dev_alloc(&p->w3f, (size_t)p->NT3 * (HID / 32) * 2 * 64 * 8);
+  e |= dev_alloc(&p->b1, HID);
+  e |= dev_alloc(&p->b2, HID);
+  e |= dev_alloc(&p->b3, p->Fs);
+  e |= dev_alloc(&p->d_frame_off, Uc + 1);
+  e |= dev_alloc(&p->d_tile_utt, max_tiles);
+  e |= dev_alloc(&p->d_tile_n0, max_tiles);
+  e |= dev_alloc(&p->d_tile_cnt, max_tiles);
+  e |= dev_alloc(&p->d_frame_utt, NTc);
+  e |= dev_alloc(&p->d_frame_loc, NTc);
+  e |= dev_alloc(&p->d_utt_seed, Uc);
+  e |= dev_alloc(&p->A1, NTc * p->Fs);
+  e |= dev_alloc(&p->P, NTc * p->Fs);
+  e |= dev_alloc(&p->normW, Uc * p->Kp);
+  e |= dev_alloc(&p->cost_frames, NTc);
+  if (e) { vaenmf_plan_destroy(p); return -2; }
+  *out = p;
+  return 0;
+}
+
+extern "C" void vaenmf_plan_destroy(vaenmf_plan* p) {
+  if (!p) return;
+  void* ptrs[] = {p->w1f, p->w2f, p->w3f, p->b1, p->b2, p->b3, p->w1y, p->d_frame_off, p->d_tile_utt, p->d_tile_n0,
+                  p->d_tile_cnt, p->d_frame_utt, p->d_frame_loc, p->d_utt_seed, p->A1, p->P, p->normW, p->cost_frames};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  delete p;
+}
+
+extern "C" int vaenmf_plan_query(const vaenmf_plan* p, int32_t what) {
+  if (!p) return -1;
+  switch (what) {
+    case VAENMF_Q_FS: return p->Fs;
+    case VAENMF_Q_KP: return p->Kp;
+    case VAENMF_Q_TILES: return p->n_tiles;
+    case VAENMF_Q_NT: return p->NT;
+    case VAENMF_Q_NUTT: return p->n_utt;
+    default: return -1;
+  }
+}
+
+extern "C" int vaenmf_set_decoder_weights(vaenmf_plan* p, const float* W1, int32_t in1, const float* b1, const float* W2,
+                                          const float* b2, const float* W3, const float* b3) {
+  VN_REQUIRE(p && W1 && b1 && W2 && b2 && W3 && b3, "null argument");
+  VN_REQUIRE(in1 >= LAT, "decoder input width %d < latent dim %d", in1, LAT);
+  const int F = p->cfg.F;
+  std::vector<uint16_t> f1 = pack_weights(W1, HID, LAT, in1, HID / 16, 1);
+  std::vector<uint16_t> f2 = pack_weights(W2, HID, HID, HID, HID / 16, HID / 32);
+  std::vector<uint16_t> f3 = pack_weights(W3, F, HID, HID, p->NT3, HID / 32);
+  std::vector<float> b3p(p->Fs, 0.f);
+  memcpy(b3p.data(), b3, sizeof(float) * F);
+  int e = 0;
+  e |= upload((uint16_t*)p->w1f, f1.data(), f1.size());
+  e |= upload((uint16_t*)p->w2f, f2.data(), f2.size());
+  e |= upload((uint16_t*)p->w3f, f3.data(), f3.size());
+  e |= upload(p->b1, b1, HID);
+  e |= upload(p->b2, b2, HID);
+  e |= upload(p->b3, b3p.data(), b3p.size());
+  if (p->w1y) { (void)hipFree(p->w1y); p->w1y = nullptr; }
+  p->Dy = in1 - LAT;
+  if (p->Dy > 0) {                             // label columns of W1, [H1][Dy]
+    std::vector<float> wy((size_t)HID * p->Dy);
+    for (int h = 0; h < HID; ++h) memcpy(&wy[(size_t)h * p->Dy], W1 + (size_t)h * in1 + LAT, sizeof(float) * p->Dy);
+    e |= dev_alloc(&p->w1y, wy.size());
+    if (!e) e |= upload(p->w1y, wy.data(), wy.size());
+  }
+  if (e) return -2;
+  p->have_weights = true;
+  return 0;
+}
+
+extern "C" int vaenmf_bind_batch(vaenmf_plan* p, int32_t n_utt, const int32_t* frame_offsets, const uint64_t* utt_seeds) {
+  VN_REQUIRE(p && frame_offsets, "null argument");
+  VN_REQUIRE(n_utt >= 1 && n_utt <= p->cfg.max_utts, "n_utt=%d exceeds capacity %d", n_utt, p->cfg.max_utts);
+  VN_REQUIRE(frame_offsets[0] == 0, "frame_offsets[0] must be 0");
+  const int NT = frame_offsets[n_utt];
+  VN_REQUIRE(NT >= 1 && NT <= p->cfg.max_frames, "total frames %d exceeds capacity %d", NT, p->cfg.max_frames);
+  std::vector<int32_t> t_utt, t_n0, t_cnt, f_utt(NT), f_loc(NT);
+  for (int u = 0; u < n_utt; ++u) {
+    const int b = frame_offsets[u], e = frame_offsets[u + 1];
+    VN_REQUIRE(e > b, "utterance %d is empty", u);
+    for (int n = b; n < e; n += FRAMES_PER_TILE) {
+      t_utt.push_back(u);
+      t_n0.push_back(n);
+      t_cnt.push_back(e - n < FRAMES_PER_TILE ? e - n : FRAMES_PER_TILE);
+    }
+    for (int n = b; n < e; ++n) { f_utt[n] = u; f_loc[n] = n - b; }
+  }
+  std::vector<uint64_t> seeds(n_utt);
+  for (int u = 0; u < n_utt; ++u) {
+    uint64_t x = 0x5EEDull + (uint64_t)u;
+    seeds[u] = utt_seeds ? utt_seeds[u] : splitmix64(x);
+  }
+  int e = 0;
+  e |= upload(p->d_frame_off, frame_offsets, (size_t)n_utt + 1);
+  e |= upload(p->d_tile_utt, t_utt.data(), t_utt.size());
+  e |= upload(p->d_tile_n0, t_n0.data(), t_n0.size());
+  e |= upload(p->d_tile_cnt, t_cnt.data(), t_cnt.size());
+  e |= upload(p->d_frame_utt, f_utt.data(), f_utt.size());
+  e |= upload(p->d_frame_loc, f_loc.data(), f_loc.size());
+  e |= upload(p->d_utt_seed, seeds.data(), seeds.size());
+  if (e) return -2;
+  p->n_utt = n_utt;
+  p->NT = NT;
+  p->n_tiles = (int)t_utt.size();
+  p->h_frame_off.assign(frame_offsets, frame_offsets + n_utt + 1);
+  return 0;
+}
+
+extern "C" int vaenmf_layer1_bias(vaenmf_plan* p, const float* y, int32_t Dy, float* B1, void* stream) {
+  VN_REQUIRE(p && y && B1, "null argument");
+  VN_REQUIRE(p->have_weights && p->NT > 0, "plan needs weights and a bound batch");
+  VN_REQUIRE(Dy == p->Dy && Dy > 0, "label width %d does not match decoder input (L+%d)", Dy, p->Dy);
+  return vaenmf_dense(y, p->NT, Dy, Dy, p->w1y, p->b1, HID, VAENMF_ACT_NONE, B1, HID, stream);
+}

@@ -1,0 +1,208 @@
+"""BatchEngine: host-side owner of the device state of a batch of utterances and
+thin caller of the C ABI (include/vaenmf.h).  PyTorch-ROCm is used only for device
+memory and streams; every numerical step of the hot path runs in libvaenmf.so."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+LAT, HID = 32, 128
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _np32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def decoder_params_from_state(sd, prefix="decoder."):
+    """Pick the decoder weights out of a state_dict in the reference key layout
+    (decoder.hidden.{i}.{weight,bias}, decoder.reconstruction.{weight,bias})."""
+    get = lambda k: _np32(sd[prefix + k].detach().cpu().numpy() if hasattr(sd[prefix + k], "detach") else sd[prefix + k])
+    n = 0
+    while (prefix + "hidden.%d.weight" % n) in sd:
+        n += 1
+    if n != 2:
+        raise NotImplementedError("this build runs decoders with 2 hidden layers (got %d)" % n)
+    return [get("hidden.0.weight"), get("hidden.0.bias"), get("hidden.1.weight"), get("hidden.1.bias"),
+            get("reconstruction.weight"), get("reconstruction.bias")]
+
+
+class BatchEngine:
+    def __init__(self, F, K, decoder, precision="bf16x3", device="cuda:0", max_frames=1 << 16, max_utts=256):
+        """decoder = [W1 (H,L+Dy), b1, W2 (H,H), b2, W3 (F,H), b3] float32 numpy (nn.Linear layout)."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("vaenmf needs a ROCm GPU (MI355X); there is no CPU path")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        W1, b1, W2, b2, W3, b3 = [_np32(a) for a in decoder]
+        if W1.shape[0] != HID or W2.shape != (HID, HID) or W3.shape != (F, HID):
+            raise NotImplementedError("this build runs decoders z(%d)+y -> %d -> %d -> F; got %s %s %s"
+                                      % (LAT, HID, HID, W1.shape, W2.shape, W3.shape))
+        self.F, self.K, self.L = int(F), int(K), LAT
+        self.Dy = W1.shape[1] - LAT
+        if self.Dy < 0:
+            raise NotImplementedError("latent dim must be %d" % LAT)
+        self.precision = {"bf16x3": _lib.PREC_BF16X3, "bf16": _lib.PREC_BF16}[precision]
+        cfg = _lib.Config(self.F, self.K, LAT, HID, HID, int(max_frames), int(max_utts), self.precision)
+        self._plan = C.c_void_p()
+        check(lib().vaenmf_plan_create(C.byref(cfg), C.byref(self._plan)))
+        check(lib().vaenmf_set_decoder_weights(self._plan, W1.ctypes.data, W1.shape[1], b1.ctypes.data, W2.ctypes.data,
+                                               b2.ctypes.data, W3.ctypes.data, b3.ctypes.data))
+        self.Fs = lib().vaenmf_plan_query(self._plan, _lib.Q_FS)
+        self.Kp = lib().vaenmf_plan_query(self._plan, _lib.Q_KP)
+        self.NT = 0
+        self.B1 = None
+
+    def close(self):
+        if getattr(self, "_plan", None):
+            lib().vaenmf_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ batch
+    def bind(self, frame_counts, Rcap, seeds=None):
+        fc = [int(n) for n in frame_counts]
+        self.frame_off = np.concatenate([[0], np.cumsum(fc)]).astype(np.int32)
+        self.U, self.NT, self.Rcap = len(fc), int(self.frame_off[-1]), int(Rcap)
+        sd = None
+        if seeds is not None:
+            sd = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64))
+        check(lib().vaenmf_bind_batch(self._plan, self.U, self.frame_off.ctypes.data, None if sd is None else sd.ctypes.data))
+        dev, f32 = self.device, torch.float32
+        NT, Fs, Kp = self.NT, self.Fs, self.Kp
+        self.X = torch.zeros(NT, Fs, 2, device=dev, dtype=f32)     # complex64, interleaved
+        self.X2 = torch.zeros(NT, Fs, device=dev, dtype=f32)
+        self.W = torch.zeros(self.U, Fs, Kp, device=dev, dtype=f32)
+        self.Ht = torch.zeros(NT, Kp, device=dev, dtype=f32)
+        self.g = torch.ones(NT, device=dev, dtype=f32)
+        self.Z = torch.zeros(NT, LAT, device=dev, dtype=f32)
+        self.Zs = torch.zeros(NT, self.Rcap, LAT, device=dev, dtype=f32)
+        self.cost_frames = torch.zeros(NT, device=dev, dtype=torch.float64)
+        self.B1 = None
+        self.d_frame_off = torch.from_numpy(self.frame_off).to(dev)
+        self.d_frame_utt = torch.repeat_interleave(torch.arange(self.U, dtype=torch.int32), torch.tensor(fc)).to(dev)
+        return self
+
+    def utt_slice(self, u):
+        return slice(int(self.frame_off[u]), int(self.frame_off[u + 1]))
+
+    def set_spectrogram(self, X):
+        """X: list of complex64 (N_u, F) numpy arrays, or a device tensor [NT,Fs,2]."""
+        if isinstance(X, torch.Tensor):
+            self.X.copy_(X)
+        else:
+            Xc = np.zeros((self.NT, self.Fs), np.complex64)
+            for u, x in enumerate(X):
+                Xc[self.utt_slice(u), :self.F] = x
+            self.X.copy_(torch.from_numpy(Xc.view(np.float32).reshape(self.NT, self.Fs, 2)))
+        check(lib().vaenmf_power_spec(_ptr(self.X), _ptr(self.X2), self.NT * self.Fs, _stream()))   # mcem.py:47
+
+    def init_nmf(self, W0, H0):
+        """W0[u] (F,K), H0[u] (K,N_u) float32 (mcem.py:42-44); g = 1."""
+        W = np.zeros((self.U, self.Fs, self.Kp), np.float32)
+        Ht = np.zeros((self.NT, self.Kp), np.float32)
+        for u in range(self.U):
+            W[u, :self.F, :self.K] = W0[u]
+            Ht[self.utt_slice(u), :self.K] = np.asarray(H0[u]).T
+        self.W.copy_(torch.from_numpy(W))
+        self.Ht.copy_(torch.from_numpy(Ht))
+        self.g.fill_(1.0)
+
+    def dense(self, x, w, b, act):
+        """act(x w^T + b) on the device (models.py:101-104 / 57-62)."""
+        M, inn = x.shape
+        out = w.shape[0]
+        y = torch.empty(M, out, device=self.device, dtype=torch.float32)
+        check(lib().vaenmf_dense(_ptr(x), M, inn, x.stride(0), _ptr(w), _ptr(b), out, act, _ptr(y), out, _stream()))
+        return y
+
+    def encode(self, enc, y=None):
+        """Z = posterior mean of encoder(|X|^2 [cat y]) (mcem.py:367-368 / :214-215).
+        enc = [(W,b)...hidden, (Wmu,bmu)] float32 numpy."""
+        x = self.X2[:, :self.F]
+        if y is not None:
+            x = torch.cat([x, y], dim=1).contiguous()
+        t = lambda a: torch.from_numpy(_np32(a)).to(self.device)
+        h = x
+        for (w, b) in enc[:-1]:
+            h = self.dense(h, t(w), t(b), _lib.ACT_TANH)
+        w, b = enc[-1]
+        self.Z.copy_(self.dense(h, t(w), t(b), _lib.ACT_NONE))
+
+    def set_labels(self, y):
+        """y device float32 [NT,Dy]: fold the label half of the first decoder layer."""
+        if self.Dy == 0:
+            raise ValueError("decoder has no label input")
+        y = y.to(self.device, torch.float32).contiguous()
+        self.B1 = torch.empty(self.NT, HID, device=self.device, dtype=torch.float32)
+        check(lib().vaenmf_layer1_bias(self._plan, _ptr(y), self.Dy, _ptr(self.B1), _stream()))
+
+    # ------------------------------------------------------------------ hot path
+    def mh_chain(self, nsamples, burnin, var_rw, call=0, eps=None, u=None, want_acc=False):
+        rng = _lib.Rng(_lib.RNG_DEVICE if eps is None else _lib.RNG_REPLAY, int(call), _ptr(eps), _ptr(u))
+        acc = torch.empty(nsamples + burnin, self.NT, device=self.device, dtype=torch.float32) if want_acc else None
+        check(lib().vaenmf_mh_chain(self._plan, _ptr(self.X2), _ptr(self.W), _ptr(self.Ht), _ptr(self.g), _ptr(self.Z),
+                                    _ptr(self.B1), _ptr(self.Zs), self.Rcap, int(nsamples), int(burnin), float(var_rw),
+                                    C.byref(rng), _ptr(acc), _stream()))
+        return acc
+
+    def rng_fill(self, call, S):
+        eps = torch.empty(S, self.NT, LAT, device=self.device, dtype=torch.float32)
+        u = torch.empty(S, self.NT, device=self.device, dtype=torch.float32)
+        check(lib().vaenmf_rng_fill(self._plan, int(call), int(S), _ptr(eps), _ptr(u), _stream()))
+        return eps, u
+
+    def decode(self, R):
+        Vs = torch.empty(self.NT, R, self.Fs, device=self.device, dtype=torch.float32)
+        check(lib().vaenmf_decode(self._plan, _ptr(self.Zs), self.Rcap, int(R), _ptr(self.B1), _ptr(Vs), _stream()))
+        return Vs
+
+    def m_step(self, R):
+        check(lib().vaenmf_m_step(self._plan, _ptr(self.X2), _ptr(self.W), _ptr(self.Ht), _ptr(self.g), _ptr(self.Zs),
+                                  self.Rcap, int(R), _ptr(self.B1), _ptr(self.cost_frames), _stream()))
+        return self.cost_frames
+
+    def wiener(self, R, want_masks=False):
+        S = torch.empty_like(self.X)
+        N = torch.empty_like(self.X)
+        WFs = torch.empty_like(self.X2) if want_masks else None
+        WFn = torch.empty_like(self.X2) if want_masks else None
+        check(lib().vaenmf_wiener(self._plan, _ptr(self.X2), _ptr(self.W), _ptr(self.Ht), _ptr(self.g), _ptr(self.Zs),
+                                  self.Rcap, int(R), _ptr(self.B1), _ptr(self.X), _ptr(S), _ptr(N), _ptr(WFs), _ptr(WFn), _stream()))
+        return S, N, WFs, WFn
+
+    def run(self, niter, nsE, biE, nsWF, biWF, var_rw):
+        """Fused EM.run for the whole batch (device RNG).  Returns (cost [U,niter] float64, S_hat, N_hat)."""
+        cost = torch.zeros(self.U, niter, device=self.device, dtype=torch.float64)
+        S = torch.empty_like(self.X)
+        N = torch.empty_like(self.X)
+        check(lib().vaenmf_em_run(self._plan, _ptr(self.X2), _ptr(self.W), _ptr(self.Ht), _ptr(self.g), _ptr(self.Z),
+                                  _ptr(self.B1), _ptr(self.Zs), self.Rcap, int(niter), int(nsE), int(biE), int(nsWF),
+                                  int(biWF), float(var_rw), _ptr(self.X), _ptr(S), _ptr(N), _ptr(cost), _stream()))
+        return cost, S, N
+
+    # ------------------------------------------------------------------ host views (reference shapes)
+    def Vb(self, u):
+        sl = self.utt_slice(u)
+        return (self.W[u, :self.F, :self.K] @ self.Ht[sl, :self.K].T)          # (F,N) mcem.py:82
+
+    def cost_from_frames(self, R):
+        """mean over (R,F,N) per utterance of the per-frame sums (mcem.py:70)."""
+        cf = self.cost_frames.cpu().numpy()
+        return np.array([cf[self.utt_slice(u)].sum() / (R * self.F * (self.frame_off[u + 1] - self.frame_off[u]))
+                         for u in range(self.U)])

@@ -1,0 +1,190 @@
+/*
+ * vaenmf.h -- C ABI of libvaenmf.so: the MI355X (gfx950) engine for the VAE-NMF
+ * "reconstruct" hot path of sp-uhh/guided-vae-nmf.
+ *
+ * The reference has no FFI boundary (it is pure Python on torch); the boundary it
+ * does have is the Python object surface that scripts/evaluate_M1.py:111-166 and
+ * scripts/evaluate_M2_vad.py:95-166 touch (python/models/mcem.py MCEM_M1/MCEM_M2,
+ * python/models/models.py, python/processing/stft.py).  Each entry point below
+ * names the reference lines it replaces; guided-vae-nmf_amd/vaenmf binds them with
+ * ctypes and re-creates that Python surface on top.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative code; vaenmf_last_error()
+ *     returns a thread-local message.  Nothing throws.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  All work is
+ *     enqueued asynchronously; no call synchronises the device unless stated.
+ *   - pointers marked DEV are device pointers owned by the caller (e.g. the
+ *     PyTorch-ROCm allocator), 16-byte aligned, never freed by the callee.
+ *     Pointers marked HOST are host memory read during the call.
+ *   - no allocation happens after vaenmf_plan_create / vaenmf_set_decoder_weights /
+ *     vaenmf_bind_batch.
+ *
+ * Data layout in HBM (all "frame-major": one row per STFT frame, frames of all
+ * utterances of the bound batch concatenated, NT = total frames)
+ *   Fs  = F rounded up to 16        (query VAENMF_Q_FS)    feature row stride
+ *   Kp  = 8, 16 or 32 (>= K)        (query VAENMF_Q_KP)    padded NMF rank
+ *   X2  float  [NT][Fs]   mixture power spectrogram |X|^2      (mcem.py:47, transposed)
+ *   X   float2 [NT][Fs]   mixture STFT, complex64              (mcem.py:46, transposed)
+ *   W   float  [U][Fs][Kp] NMF dictionary per utterance        (mcem.py:48)  pad = 0
+ *   Ht  float  [NT][Kp]   NMF activations, transposed          (mcem.py:49)  pad = 0
+ *   g   float  [NT]       per-frame gain                       (mcem.py:51)
+ *   Z   float  [NT][L]    last draw of the latent variables    (mcem.py:368, transposed)
+ *   Zs  float  [NT][Rcap][L] posterior samples                 (mcem.py:386)
+ *   B1  float  [NT][H1]   per-frame first-layer bias b1 + W1[:,L:] y_n  (M2: the label
+ *                         part of decoder(cat([Z,y])) folded once, mcem.py:242); NULL = M1
+ */
+#ifndef VAENMF_H
+#define VAENMF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vaenmf_plan vaenmf_plan;
+
+enum { VAENMF_PREC_BF16X3 = 0,   /* bf16 MFMA, 3-term hi/lo split, fp32 accumulate (~fp32 accuracy) */
+       VAENMF_PREC_BF16   = 1 }; /* plain bf16 MFMA, fp32 accumulate                                   */
+
+enum { VAENMF_RNG_REPLAY = 0,    /* caller supplies the normal / uniform draws (parity runs)          */
+       VAENMF_RNG_DEVICE = 1 };  /* counter-seeded xoshiro128+ / Box-Muller streams on the device     */
+
+enum { VAENMF_Q_FS = 0, VAENMF_Q_KP = 1, VAENMF_Q_TILES = 2, VAENMF_Q_NT = 3, VAENMF_Q_NUTT = 4 };
+
+enum { VAENMF_ACT_NONE = 0, VAENMF_ACT_TANH = 1, VAENMF_ACT_RELU = 2, VAENMF_ACT_SIGMOID = 3 };
+
+typedef struct {
+  int32_t F;          /* frequency bins, n_fft/2+1 (<= 640)                         */
+  int32_t K;          /* NMF rank (<= 32)                                           */
+  int32_t L;          /* latent dimension (this build: 32)                          */
+  int32_t H1, H2;     /* decoder hidden sizes, first and second layer (this build: 128,128) */
+  int32_t max_frames; /* capacity: total frames of a bound batch                    */
+  int32_t max_utts;   /* capacity: utterances of a bound batch                      */
+  int32_t precision;  /* VAENMF_PREC_*                                              */
+} vaenmf_config;
+
+typedef struct {
+  int32_t  mode;        /* VAENMF_RNG_*                                             */
+  uint32_t call;        /* chain-invocation counter (EM iteration index; WF = niter) */
+  const float* eps;     /* DEV [S][NT][L] N(0,1) draws, step-major   (REPLAY only; mcem.py:407) */
+  const float* u;       /* DEV [S][NT]    U(0,1) draws               (REPLAY only; mcem.py:420) */
+} vaenmf_rng;
+
+const char* vaenmf_last_error(void);
+
+/* Plan = shapes + device-resident decoder weights + batch tiling + workspace. */
+int  vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out);
+void vaenmf_plan_destroy(vaenmf_plan* p);
+int  vaenmf_plan_query(const vaenmf_plan* p, int32_t what);
+
+/* Decoder weights, HOST, nn.Linear layout [out][in] row-major as in the state_dict
+ * keys decoder.hidden.{0,1}.{weight,bias}, decoder.reconstruction.{weight,bias}
+ * (models.py:107-121).  in1 = L + Dy; the first L columns of W1 feed the MFMA path,
+ * the remaining Dy columns are kept for vaenmf_layer1_bias. */
+int vaenmf_set_decoder_weights(vaenmf_plan* p, const float* W1, int32_t in1, const float* b1,
+                               const float* W2, const float* b2, const float* W3, const float* b3);
+
+/* Bind a batch: frame_offsets HOST [n_utt+1] (frames of utterance u are rows
+ * frame_offsets[u] .. frame_offsets[u+1]-1); utt_seeds HOST [n_utt] or NULL (device RNG
+ * streams are keyed by (utt seed, frame index within the utterance), so results do not
+ * depend on how utterances are batched). */
+int vaenmf_bind_batch(vaenmf_plan* p, int32_t n_utt, const int32_t* frame_offsets,
+                      const uint64_t* utt_seeds);
+
+/* B1[n][h] = b1[h] + sum_d W1[h][L+d] * y[n][d]   (label half of mcem.py:242/261/283).
+ * y DEV [NT][Dy]. */
+int vaenmf_layer1_bias(vaenmf_plan* p, const float* y, int32_t Dy, float* B1, void* stream);
+
+/* Metropolis-Hastings chain of one E-step / Wiener phase -- replaces
+ * MCEM_M1.sample_posterior (mcem.py:371-441) and MCEM_M2.sample_posterior (:218-294):
+ * nsamples+burnin random-walk steps per frame, samples after burn-in to Zs[:, 0..nsamples-1, :],
+ * Z overwritten with the last draw (mcem.py:466).  acc_out (DEV [S][NT], may be NULL)
+ * receives the log-acceptance of every step (mcem.py:415-417) for parity tests. */
+int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, const float* Ht, const float* g,
+                    float* Z, const float* B1, float* Zs, int32_t Rcap,
+                    int32_t nsamples, int32_t burnin, float var_rw,
+                    const vaenmf_rng* rng, float* acc_out, void* stream);
+
+/* The draws the DEVICE generator hands to step s of chain invocation rng->call:
+ * eps_out DEV [S][NT][L], u_out DEV [S][NT].  Test/debug aid: a REPLAY run fed with
+ * these buffers is bit-identical to the DEVICE run. */
+int vaenmf_rng_fill(vaenmf_plan* p, uint32_t call, int32_t S, float* eps_out, float* u_out, void* stream);
+
+/* Vs = decoder(Z_samples): replaces compute_Vs (mcem.py:444-454 / :297-307).
+ * Vs_out DEV [NT][R][Fs] (the reference's (R,F,N) tensor, frame-major). */
+int vaenmf_decode(vaenmf_plan* p, const float* Zs, int32_t Rcap, int32_t R, const float* B1,
+                  float* Vs_out, void* stream);
+
+/* One M-step -- replaces EM.M_step (mcem.py:90-152) plus
+ * compute_expected_neg_log_like (:68-70): multiplicative updates of W, H (exponent 1/2),
+ * L1 column normalisation, gain update.  The R posterior samples are re-decoded on
+ * chip instead of being streamed from HBM.  W, Ht, g are updated in place.
+ * cost_frames DEV [NT] double: sum_{r,f}(log Vx + X2/Vx) per frame (after the update);
+ * the mean over (R,F,N) of an utterance is mcem.py:70. */
+int vaenmf_m_step(vaenmf_plan* p, const float* X2, float* W, float* Ht, float* g,
+                  const float* Zs, int32_t Rcap, int32_t R, const float* B1,
+                  double* cost_frames, void* stream);
+
+/* Wiener filter from the R samples in Zs -- replaces compute_WF's averaging
+ * (mcem.py:486-488) and the complex products of EM.run (:175-176):
+ * S_hat = mean_r(g Vs/Vx) * X,  N_hat = mean_r(Vb/Vx) * X.   X, S_hat, N_hat DEV
+ * complex64 [NT][Fs] (interleaved re,im); WFs/WFn DEV [NT][Fs] optional (NULL). */
+int vaenmf_wiener(vaenmf_plan* p, const float* X2, const float* W, const float* Ht, const float* g,
+                  const float* Zs, int32_t Rcap, int32_t R, const float* B1,
+                  const float* X, float* S_hat, float* N_hat, float* WFs, float* WFn, void* stream);
+
+/* Fused driver -- replaces EM.run (mcem.py:155-178) for the whole bound batch with no
+ * host synchronisation per iteration: niter x (E-step, M-step, cost), then the Wiener
+ * chain and filter.  cost DEV [n_utt][niter] double.  (nsE, biE) / (nsWF, biWF) are the
+ * EFFECTIVE sample/burn-in counts (the caller applies MCEM_M1's positional-shift quirk,
+ * mcem.py:461-462).  Device RNG only (rng_mode REPLAY is served step by step by the
+ * calls above). */
+int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* Ht, float* g, float* Z,
+                  const float* B1, float* Zs, int32_t Rcap, int32_t niter,
+                  int32_t nsE, int32_t biE, int32_t nsWF, int32_t biWF, float var_rw,
+                  const float* X, float* S_hat, float* N_hat, double* cost, void* stream);
+
+/* Dense layer Y = act(X Wt^T + b): encoder / classifier forwards
+ * (models.py:101-104, 33-38, 57-62).  X DEV [M][in], Wt DEV [out][in], b DEV [out],
+ * Y DEV [M][ldy] (first `out` columns written). */
+int vaenmf_dense(const float* X, int32_t M, int32_t in, int32_t ldx, const float* Wt, const float* b,
+                 int32_t out, int32_t act, float* Y, int32_t ldy, void* stream);
+
+/* |X|^2 (mcem.py:47): X DEV complex64 [n], X2 DEV float [n]. */
+int vaenmf_power_spec(const float* X, float* X2, int64_t n, void* stream);
+
+/* STFT front end -- replaces python/processing/stft.py:16-63 (librosa.core.stft with
+ * center=True, reflect padding, periodic Hann).  vaenmf_stft_num_frames applies the
+ * integer-window check (:37-38) and the end-pad rule (:48-53) on the host and returns
+ * n_fft, hop, the frame count and the padded length of one utterance.
+ * vaenmf_stft_batch: wav DEV float [sum T]; sample_offsets DEV int64 [n_utt+1];
+ * frame_offsets DEV int32 [n_utt+1]; frame_utt DEV int32 [NT]; padded_len DEV int32
+ * [n_utt]; X DEV complex64 [NT][Fs] (bins >= F zeroed).  nfft: power of two <= 2048.
+ * The transform runs in float64 and is rounded once to complex64 like the reference. */
+int vaenmf_stft_num_frames(int64_t n_samples, double fs, double wlen_sec, double hop_percent,
+                           int32_t* nfft, int32_t* hop, int32_t* n_frames, int32_t* n_padded);
+int vaenmf_stft_batch(const float* wav, int32_t n_frames_total, const int64_t* sample_offsets,
+                      const int32_t* frame_offsets, const int32_t* frame_utt,
+                      const int32_t* padded_len, int32_t nfft, int32_t hop, int32_t Fs,
+                      float* X, void* stream);
+/* iSTFT back end -- replaces stft.py:66-102 (librosa.core.istft with length=max_len,
+ * window-sum-square normalised overlap-add): S DEV complex64 [NT][Fs] -> wav_out DEV
+ * float [sum T] (T = sample_offsets[u+1]-sample_offsets[u] = max_len of utterance u);
+ * work DEV float [NT][nfft] scratch. */
+int vaenmf_istft_batch(const float* S, int32_t n_utt, int32_t n_frames_total,
+                       const int64_t* sample_offsets, const int32_t* frame_offsets,
+                       int32_t nfft, int32_t hop, int32_t Fs, float* work, float* wav_out,
+                       void* stream);
+
+/* SI-SDR sufficient statistics -- python/metrics.py:12-60: per utterance the Gram
+ * matrix of (s_hat, s, n) in float64: out DEV [n_utt][6] =
+ * {<sh,sh>, <sh,s>, <sh,n>, <s,s>, <s,n>, <n,n>}; sample_offsets DEV int64 [n_utt+1]. */
+int vaenmf_gram3_batch(const float* s_hat, const float* s, const float* n, int32_t n_utt,
+                       const int64_t* sample_offsets, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAENMF_H */

@@ -1,0 +1,320 @@
+"""GPU parity tests: the HIP path (through the C ABI, libvaenmf.so) against the numpy
+oracle and the golden vectors generated from the reference.
+
+Stated tolerances (float32 unless noted):
+  * decoder variances Vs, bf16x3 mode: 2e-4 relative (split-bf16 MFMA products carry
+    ~2^-17 relative error per product; fp32 reference ~2^-24);  bf16 mode: 5e-2.
+  * MH log-acceptance (mcem.py:415-417): 2e-3 absolute (sum of ~F terms).
+  * W, H, g after an M-step from identical samples: 5e-4 relative; cost: 1e-4 relative.
+  * trajectories with replayed noise: decisions identical on the golden cases (they were
+    chosen with decision margins >= 1e-3), final S_hat 2e-3 relative (L2).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import vaenmf_oracle as orc
+from helpers import load_case, rel_err, nrm_err, GOLDEN
+
+
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def dec_list(params):
+    return [params["decoder.hidden.0.weight"], params["decoder.hidden.0.bias"], params["decoder.hidden.1.weight"],
+            params["decoder.hidden.1.bias"], params["decoder.reconstruction.weight"], params["decoder.reconstruction.bias"]]
+
+
+def make_engine(params, F, K, counts_N, Rcap, precision="bf16x3", seeds=None):
+    from vaenmf.engine import BatchEngine
+    eng = BatchEngine(F, K, dec_list(params), precision=precision, max_frames=sum(counts_N), max_utts=len(counts_N))
+    eng.bind(counts_N, Rcap=Rcap, seeds=seeds)
+    return eng
+
+
+@pytest.mark.parametrize("F,precision,tol", [(65, "bf16x3", 2e-4), (257, "bf16x3", 2e-4), (513, "bf16x3", 2e-4),
+                                             (257, "bf16", 5e-2)])
+def test_decoder_forward(F, precision, tol):
+    """compute_Vs (mcem.py:444-454): Vs = decoder(Z_samples), ragged batch, R not a multiple of 16."""
+    need_gpu()
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=3, bias_std=0.1)
+    counts, R = [5, 33, 17], 21
+    eng = make_engine(params, F, 4, counts, Rcap=24, precision=precision)
+    g = np.random.default_rng(0)
+    Zs = g.standard_normal((sum(counts), 24, 32)).astype(np.float32)
+    eng.Zs.copy_(torch.from_numpy(Zs))
+    Vs = eng.decode(R).cpu().numpy()
+    ref = orc.decoder_forward(params, Zs[:, :R].reshape(-1, 32)).reshape(sum(counts), R, F)
+    assert rel_err(Vs[:, :, :F], ref) < tol
+    assert np.all(Vs[:, :, F:] == 0)
+
+
+def test_decoder_forward_m2_label_bias():
+    """decoder(cat([Z, y])) (mcem.py:242): the label half folded into a per-frame bias."""
+    need_gpu()
+    F, Dy = 65, 65
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=4, y_dim=Dy, bias_std=0.1)
+    counts, R = [19, 40], 10
+    eng = make_engine(params, F, 4, counts, Rcap=R)
+    g = np.random.default_rng(1)
+    NT = sum(counts)
+    Zs = g.standard_normal((NT, R, 32)).astype(np.float32)
+    y = (g.random((NT, Dy)) > 0.5).astype(np.float32)
+    eng.Zs.copy_(torch.from_numpy(Zs))
+    eng.set_labels(torch.from_numpy(y))
+    Vs = eng.decode(R).cpu().numpy()
+    zin = np.concatenate([Zs, np.broadcast_to(y[:, None, :], (NT, R, Dy))], 2)
+    ref = orc.decoder_forward(params, zin.reshape(NT * R, -1)).reshape(NT, R, F)
+    assert rel_err(Vs[:, :, :F], ref) < 2e-4
+
+
+def setup_from_case(name, model, precision="bf16x3"):
+    z, params, draws, meta = load_case(name)
+    nsE, biE, nsW, biW = meta["counts"]
+    o = orc.MCEMOracle(model, meta["niter"], nsE, biE, nsW, biW, 0.01, reference_compat=True)
+    rng = orc.ReplayRNG(draws)
+    y = z["y"] if model == "M2" else None
+    o.init_parameters(z["X"], params, meta["K"], 1e-8, rng, y=y)
+    ns, bi = o.e_step_counts()
+    nw, bw = o.wf_counts()
+    eng = make_engine(params, meta["F"], meta["K"], [meta["N"]], Rcap=max(ns, nw), precision=precision)
+    eng.set_spectrogram([z["X"]])
+    eng.init_nmf([z["W0"]], [z["H0"]])
+    if y is not None:
+        eng.set_labels(torch.from_numpy(y))
+    eng.Z.copy_(torch.from_numpy(np.ascontiguousarray(z["Z0"].T)))
+    return z, params, meta, o, rng, eng
+
+
+def replay_buffers(rng, S, N, L, dev):
+    """Take the next S (randn(L,N), rand(N)) pairs of the recorded stream."""
+    eps = np.empty((S, N, L), np.float32)
+    u = np.empty((S, N), np.float32)
+    for m in range(S):
+        eps[m] = rng.draws[rng.pos].T
+        u[m] = rng.draws[rng.pos + 1]
+        rng.pos += 2
+    return torch.from_numpy(eps).to(dev), torch.from_numpy(u).to(dev)
+
+
+CASES = [("m1_f65", "M1"), ("m2_vad_f65", "M2"), ("m2_ibm_f65", "M2"), ("m1_f257", "M1")]
+
+
+@pytest.mark.parametrize("name,model", CASES)
+def test_encoder_init(name, model):
+    """Z = mu_enc(|X|^2 [cat y]) (mcem.py:367-368 / :214-215) via vaenmf_dense."""
+    need_gpu()
+    z, params, meta, o, rng, eng = setup_from_case(name, model)
+    enc = [(params["encoder.hidden.0.weight"], params["encoder.hidden.0.bias"]),
+           (params["encoder.hidden.1.weight"], params["encoder.hidden.1.bias"]),
+           (params["encoder.sample.mu.weight"], params["encoder.sample.mu.bias"])]
+    y = torch.from_numpy(z["y"]).to(eng.device) if model == "M2" else None
+    eng.encode(enc, y)
+    assert np.max(np.abs(eng.Z.cpu().numpy().T - z["Z0"])) < 2e-5
+    assert rel_err(eng.X2[:, :meta["F"]].cpu().numpy().T, o.X_abs_2) < 1e-6
+
+
+@pytest.mark.parametrize("name,model", CASES)
+def test_first_em_iteration(name, model):
+    """E-step chain (every log-acceptance, every decision, the samples), then the M-step,
+    against the reference's recorded first iteration."""
+    need_gpu()
+    z, params, meta, o, rng, eng = setup_from_case(name, model)
+    ns, bi = o.e_step_counts()
+    S, N, F, K = ns + bi, meta["N"], meta["F"], meta["K"]
+    pos0 = rng.pos
+    eps, u = replay_buffers(rng, S, N, 32, eng.device)
+    acc = eng.mh_chain(ns, bi, 0.01, eps=eps, u=u, want_acc=True).cpu().numpy()
+    ref_acc = z["acc"][:S]
+    assert np.max(np.abs(acc - ref_acc)) < 2e-3
+    dec_gpu = np.log(u.cpu().numpy()) < acc
+    dec_ref = np.log(u.cpu().numpy()) < ref_acc
+    assert np.array_equal(dec_gpu, dec_ref)
+    # oracle chain on the same draws
+    rng.pos = pos0
+    Zs_ref = o.sample_posterior(o.Z, ns, bi)
+    assert np.max(np.abs(eng.Zs[:, :ns].cpu().numpy() - Zs_ref)) < 1e-6
+    assert np.max(np.abs(eng.Z.cpu().numpy().T - z["E1_Z"])) < 1e-5
+    Vs = eng.decode(ns).cpu().numpy()[:, :, :F]                    # [N,R,F]
+    assert rel_err(np.moveaxis(Vs, 0, -1), z["E1_Vs"]) < 2e-4
+    # M-step
+    eng.m_step(ns)
+    W = eng.W[0, :F, :K].cpu().numpy()
+    H = eng.Ht[:, :K].cpu().numpy().T
+    assert rel_err(W, z["M1_W"]) < 5e-4
+    assert rel_err(H, z["M1_H"]) < 5e-4
+    assert rel_err(eng.g.cpu().numpy(), z["M1_g"]) < 5e-4
+    assert rel_err(eng.Vb(0).cpu().numpy(), z["M1_Vb"]) < 5e-4
+    cost = eng.cost_from_frames(ns)[0]
+    assert abs(cost - z["cost"][0]) / abs(z["cost"][0]) < 1e-4
+    # padding stays clean
+    assert float(eng.W[0, F:].abs().max()) == 0 if eng.Fs > F else True
+    assert float(eng.Ht[:, K:].abs().max()) == 0 if eng.Kp > K else True
+
+
+@pytest.mark.parametrize("name,model", CASES)
+def test_full_run_replay(name, model):
+    """EM.run (mcem.py:155-178) step by step with the reference's recorded noise."""
+    need_gpu()
+    z, params, meta, o, rng, eng = setup_from_case(name, model)
+    ns, bi = o.e_step_counts()
+    nw, bw = o.wf_counts()
+    N, F = meta["N"], meta["F"]
+    cost = np.zeros(meta["niter"])
+    for it in range(meta["niter"]):
+        eps, u = replay_buffers(rng, ns + bi, N, 32, eng.device)
+        eng.mh_chain(ns, bi, 0.01, eps=eps, u=u)
+        eng.m_step(ns)
+        cost[it] = eng.cost_from_frames(ns)[0]
+    eps, u = replay_buffers(rng, nw + bw, N, 32, eng.device)
+    eng.mh_chain(nw, bw, 0.01, eps=eps, u=u)
+    S, Nn, WFs, WFn = eng.wiener(nw, want_masks=True)
+    assert rng.pos == len(rng.draws)
+    assert np.max(np.abs(cost - z["cost"]) / np.abs(z["cost"])) < 2e-4
+    to_c = lambda t: np.ascontiguousarray(t[:, :F].cpu().numpy()).view(np.complex64).reshape(N, F).T
+    assert nrm_err(to_c(S), z["S_hat"]) < 2e-3
+    assert nrm_err(to_c(Nn), z["N_hat"]) < 2e-3
+    assert rel_err(WFs[:, :F].cpu().numpy().T, z["WFs"]) < 5e-3
+    assert np.max(np.abs(eng.Z.cpu().numpy().T - z["Z"])) < 1e-5
+    assert rel_err(eng.W[0, :F, :meta["K"]].cpu().numpy(), z["W"]) < 2e-3
+    assert rel_err(eng.g.cpu().numpy(), z["g"]) < 2e-3
+
+
+def test_mirror_classes_match_reference_surface():
+    """MCEM_M1 drop-in surface (mcem.py:350-369, :155-178) with rng='replay': draws come
+    from torch's global generator in the reference's order."""
+    need_gpu()
+    import vaenmf
+    z, params, draws, meta = load_case("m1_f65")
+    nsE, biE, nsW, biW = meta["counts"]
+    vae = vaenmf.VariationalAutoencoder([meta["F"], meta["L"], [128, 128]])
+    vae.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+    m = vaenmf.MCEM_M1(niter=meta["niter"], nsamples_E_step=nsE, burnin_E_step=biE, nsamples_WF=nsW, burnin_WF=biW,
+                       var_RW=0.01)
+    torch.manual_seed(int(z["seed"]))          # the seed the golden script used for the reference run
+    m.init_parameters(X=z["X"], vae=vae, nmf_rank=meta["K"], eps=1e-8, device="cuda:0")
+    assert rel_err(m.W.cpu().numpy(), z["W0"]) == 0        # same generator, same draw order
+    cost = m.run()
+    assert cost.dtype == np.float64 and cost.shape == (meta["niter"],)
+    assert np.max(np.abs(cost - z["cost"]) / np.abs(z["cost"])) < 2e-4
+    assert m.S_hat.dtype == np.complex64 and m.S_hat.shape == (meta["F"], meta["N"])
+    assert nrm_err(m.S_hat, z["S_hat"]) < 2e-3
+    assert nrm_err(m.N_hat, z["N_hat"]) < 2e-3
+    with pytest.raises(NameError):
+        RVAE = type("RVAE", (), {})
+        m.init_parameters(X=z["X"], vae=RVAE(), nmf_rank=4, eps=1e-8, device="cuda:0")
+
+
+def test_device_rng_streams():
+    """On-device generator: (i) rng_fill is reproducible and batching-independent,
+    (ii) moments are right, (iii) a REPLAY run fed with rng_fill's buffers is
+    bit-identical to the DEVICE run."""
+    need_gpu()
+    z, params, draws, meta = load_case("m1_f257")
+    F, K = meta["F"], meta["K"]
+    counts = [40, 70, 33]
+    seeds = [11, 22, 33]
+    g = np.random.default_rng(5)
+    Xs = [(g.standard_normal((n, F)) + 1j * g.standard_normal((n, F))).astype(np.complex64) for n in counts]
+
+    def fresh(cnts, sds, xs):
+        eng = make_engine(params, F, K, cnts, Rcap=8, seeds=sds)
+        eng.set_spectrogram(xs)
+        eng.init_nmf([np.maximum(g2.random((F, K)), 1e-8).astype(np.float32) for _ in cnts],
+                     [np.maximum(g2.random((K, n)), 1e-8).astype(np.float32) for n in cnts])
+        return eng
+
+    g2 = np.random.default_rng(6)
+    eng = fresh(counts, seeds, Xs)
+    S = 20
+    eps, u = eng.rng_fill(3, S)
+    e = eps.cpu().numpy()
+    assert abs(e.mean()) < 0.01 and abs(e.std() - 1) < 0.01 and abs(u.cpu().numpy().mean() - 0.5) < 0.02
+    assert abs((e ** 4).mean() - 3.0) < 0.15
+    # batching independence: utterance 1 alone gets the same streams
+    g2 = np.random.default_rng(6)
+    eng1 = fresh([counts[1]], [seeds[1]], [Xs[1]])
+    eps1, u1 = eng1.rng_fill(3, S)
+    sl = eng.utt_slice(1)
+    assert torch.equal(eps[:, sl], eps1) and torch.equal(u[:, sl], u1)
+    # device == replay(rng_fill)
+    Z0 = eng.Z.clone()
+    eng.mh_chain(8, 12, 0.01, call=3)
+    Zs_dev, Z_dev = eng.Zs.clone(), eng.Z.clone()
+    eng.Z.copy_(Z0)
+    eng.mh_chain(8, 12, 0.01, eps=eps, u=u)
+    assert torch.equal(eng.Zs, Zs_dev) and torch.equal(eng.Z, Z_dev)
+    assert float((Z_dev - Z0).abs().max()) > 0      # chains moved
+
+
+def test_fused_run_equals_stepwise_and_batches_are_independent():
+    """vaenmf_em_run (no host sync) == the same kernels called step by step; an utterance
+    gives the same result alone and inside a ragged batch (device RNG keyed per utterance)."""
+    need_gpu()
+    z, params, draws, meta = load_case("m1_f257")
+    F, K = meta["F"], meta["K"]
+    counts, seeds = [37, 64, 50], [5, 6, 7]
+    g = np.random.default_rng(8)
+    Xs = [((g.standard_normal((n, F)) + 1j * g.standard_normal((n, F))) * (1 + 3 * np.exp(-np.arange(F) / 40.0))).astype(np.complex64) for n in counts]
+    W0 = [np.maximum(g.random((F, K)), 1e-8).astype(np.float32) for _ in counts]
+    H0 = [np.maximum(g.random((K, n)), 1e-8).astype(np.float32) for n in counts]
+    enc = [(params["encoder.hidden.0.weight"], params["encoder.hidden.0.bias"]),
+           (params["encoder.hidden.1.weight"], params["encoder.hidden.1.bias"]),
+           (params["encoder.sample.mu.weight"], params["encoder.sample.mu.bias"])]
+
+    def prep(idx):
+        eng = make_engine(params, F, K, [counts[i] for i in idx], Rcap=12, seeds=[seeds[i] for i in idx])
+        eng.set_spectrogram([Xs[i] for i in idx])
+        eng.init_nmf([W0[i] for i in idx], [H0[i] for i in idx])
+        eng.encode(enc)
+        return eng
+
+    niter, nsE, biE, nsW, biW = 3, 6, 5, 12, 7
+    eng = prep([0, 1, 2])
+    cost, S, N = eng.run(niter, nsE, biE, nsW, biW, 0.01)
+    cost = cost.cpu().numpy()
+    assert np.all(np.isfinite(cost)) and np.all(np.isfinite(S.cpu().numpy()))
+    # step by step
+    eng2 = prep([0, 1, 2])
+    c2 = np.zeros((3, niter))
+    for it in range(niter):
+        eng2.mh_chain(nsE, biE, 0.01, call=it)
+        eng2.m_step(nsE)
+        c2[:, it] = eng2.cost_from_frames(nsE)
+    eng2.mh_chain(nsW, biW, 0.01, call=niter)
+    S2, N2, _, _ = eng2.wiener(nsW)
+    assert torch.equal(S, S2) and torch.equal(N, N2)
+    assert np.max(np.abs(c2 - cost) / np.abs(cost)) < 1e-12
+    # utterance 1 alone
+    eng3 = prep([1])
+    cost3, S3, N3 = eng3.run(niter, nsE, biE, nsW, biW, 0.01)
+    sl = eng.utt_slice(1)
+    assert torch.equal(S[sl], S3) and np.array_equal(cost[1], cost3.cpu().numpy()[0])
+
+
+def test_stft_istft_and_metrics():
+    """stft.py:16-63 / :66-102 on the GPU vs the oracle, on reference-committed audio;
+    metrics.py:39-60 known answer (-6.2 / -4.3 / -1.9 dB)."""
+    need_gpu()
+    from vaenmf import stft as vstft, metrics as vmet
+    zz = np.load(GOLDEN + "/metrics_dummy_m2.npz")
+    x = zz["a_s"] / 32768.0
+    for wlen in (64e-3, 32e-3):
+        X = vstft.stft(x, fs=16000, wlen_sec=wlen, hop_percent=0.25)
+        Xo = orc.stft(x, fs=16000, wlen_sec=wlen, hop_percent=0.25)
+        assert X.shape == Xo.shape and X.dtype == np.complex64
+        assert np.max(np.abs(X - Xo)) < 2e-6 * np.max(np.abs(Xo))
+        xr = vstft.istft(X, fs=16000, wlen_sec=wlen, hop_percent=0.25, max_len=len(x))
+        assert xr.dtype == np.float32 and len(xr) == len(x)
+        assert np.max(np.abs(xr - x)) < 2e-6
+        xo = orc.istft(Xo, fs=16000, wlen_sec=wlen, hop_percent=0.25, max_len=len(x) + 700)
+        xr2 = vstft.istft(Xo, fs=16000, wlen_sec=wlen, hop_percent=0.25, max_len=len(x) + 700)
+        assert np.max(np.abs(xr2 - xo)) < 2e-6
+    with pytest.raises(ValueError):
+        vstft.stft(x, fs=16000, wlen_sec=50.01e-3)
+    r = vmet.energy_ratios(zz["a_s_est"] / 32768.0, zz["a_s"] / 32768.0, zz["a_n"] / 32768.0)
+    assert np.allclose(r, zz["a_ratios"], atol=1e-6)
