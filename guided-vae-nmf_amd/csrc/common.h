@@ -56,6 +56,23 @@ struct vaenmf_plan {
   float* normW;              // [n_utt][Kp]
   double* cost_frames;       // [NT] (fused driver)
   int n_sms;
+  // optional per-kernel timing with HIP events on the launch stream (vaenmf_profile_*)
+  bool prof_on;
+  std::vector<hipEvent_t> prof_ev;      // pairs (start, stop)
+  std::vector<int> prof_kind;
+  size_t prof_used;
+};
+
+enum { VN_K_CHAIN = 0, VN_K_WSTATS = 1, VN_K_WUPDATE = 2, VN_K_HG = 3, VN_K_WF = 4, VN_K_NKINDS = 5 };
+struct ProfScope {   // records a (start, stop) event pair around a launch when profiling is on
+  vaenmf_plan* p; hipStream_t st; size_t idx; bool on;
+  ProfScope(vaenmf_plan* p_, int kind, hipStream_t st_) : p(p_), st(st_), idx(0), on(false) {
+    if (p && p->prof_on && p->prof_used + 2 <= p->prof_ev.size()) {
+      on = true; idx = p->prof_used; p->prof_used += 2; p->prof_kind[idx / 2] = kind;
+      (void)hipEventRecord(p->prof_ev[idx], st);
+    }
+  }
+  ~ProfScope() { if (on) (void)hipEventRecord(p->prof_ev[idx + 1], st); }
 };
 
 // ---- device helpers --------------------------------------------------------

@@ -188,7 +188,7 @@ struct ChainArgs {
   const int32_t *tile_utt, *tile_n0, *tile_cnt, *frame_off;
   const uint64_t* utt_seed;
   const float *eps, *u;      // replay buffers or null
-  int Fs, Kp, NT, Rcap, nsamples, burnin, rng_mode;
+  int Fs, Kp, NT, Rcap, nsamples, burnin, rng_mode, update_Z;
   uint32_t call;
   float sd;                  // sqrt(var_RW)
 };
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
       }
     }
   }
-  if (w == 0) {                                       // self.Z = last draw (mcem.py:466)
+  if (w == 0 && a.update_Z) {                         // self.Z = last draw (mcem.py:466)
 #pragma unroll
     for (int fg = 0; fg < 2; ++fg)
       if (fvalid[fg]) {
@@ -787,8 +787,8 @@ int vn_launch_w_update(const vaenmf_plan* p, float* W, const float* Ht, hipStrea
 int vn_launch_cost_reduce(const vaenmf_plan* p, const double* cost_frames, int R, double* cost, int niter, int it, hipStream_t st);
 
 extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, const float* Ht, const float* g,
-                               float* Z, const float* B1, float* Zs, int32_t Rcap, int32_t nsamples, int32_t burnin,
-                               float var_rw, const vaenmf_rng* rng, float* acc_out, void* stream) {
+                               float* Z, int32_t update_Z, const float* B1, float* Zs, int32_t Rcap, int32_t nsamples,
+                               int32_t burnin, float var_rw, const vaenmf_rng* rng, float* acc_out, void* stream) {
   if (int e = check_bound(p)) return e;
   VN_REQUIRE(rng != nullptr, "rng is null");
   VN_REQUIRE(nsamples >= 1 && burnin >= 0 && nsamples <= Rcap, "bad sample counts (nsamples=%d burnin=%d Rcap=%d)", nsamples, burnin, Rcap);
@@ -799,9 +799,10 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
   a.tile_utt = p->d_tile_utt; a.tile_n0 = p->d_tile_n0; a.tile_cnt = p->d_tile_cnt; a.frame_off = p->d_frame_off;
   a.utt_seed = p->d_utt_seed; a.eps = rng->eps; a.u = rng->u;
   a.Fs = p->Fs; a.Kp = p->Kp; a.NT = p->NT; a.Rcap = Rcap; a.nsamples = nsamples; a.burnin = burnin;
-  a.rng_mode = rng->mode; a.call = rng->call; a.sd = sqrtf(var_rw);
+  a.rng_mode = rng->mode; a.call = rng->call; a.sd = sqrtf(var_rw); a.update_Z = update_Z;
   hipStream_t st = (hipStream_t)stream;
   const bool split = p->cfg.precision == VAENMF_PREC_BF16X3;
+  ProfScope ps(p, VN_K_CHAIN, st);
   if (p->nwaves == 4) { if (split) launch_chain<4, true>(a, p->n_tiles, st); else launch_chain<4, false>(a, p->n_tiles, st); }
   else                { if (split) launch_chain<8, true>(a, p->n_tiles, st); else launch_chain<8, false>(a, p->n_tiles, st); }
   VN_CHECK_HIP(hipGetLastError());
@@ -834,9 +835,9 @@ extern "C" int vaenmf_m_step(vaenmf_plan* p, const float* X2, float* W, float* H
   DecodeArgs a = base_decode_args(p, Zs, Rcap, R, B1);
   a.X2 = X2; a.W = W; a.Ht = Ht; a.g = g; a.A1 = p->A1; a.P = p->P; a.normW = p->normW;
   a.cost_frames = cost_frames ? cost_frames : p->cost_frames;
-  launch_decode<MODE_WSTATS>(p, a, st);                 // A1, X2*A2 per (frame, bin)
-  if (int e = vn_launch_w_update(p, W, Ht, st)) return e;  // W <- W sqrt(num/den), L1 column norms
-  launch_decode<MODE_HG>(p, a, st);                     // H, g, cost
+  { ProfScope ps(p, VN_K_WSTATS, st); launch_decode<MODE_WSTATS>(p, a, st); }   // A1, X2*A2 per (frame, bin)
+  { ProfScope ps(p, VN_K_WUPDATE, st); if (int e = vn_launch_w_update(p, W, Ht, st)) return e; }  // W <- W sqrt(num/den), L1 norms
+  { ProfScope ps(p, VN_K_HG, st); launch_decode<MODE_HG>(p, a, st); }           // H, g, cost
   VN_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -849,7 +850,7 @@ extern "C" int vaenmf_wiener(vaenmf_plan* p, const float* X2, const float* W, co
   DecodeArgs a = base_decode_args(p, Zs, Rcap, R, B1);
   a.X2 = X2; a.W = W; a.Ht = const_cast<float*>(Ht); a.g = const_cast<float*>(g); a.X = X;
   a.S_hat = S_hat; a.N_hat = N_hat; a.WFs = WFs; a.WFn = WFn;
-  launch_decode<MODE_WF>(p, a, (hipStream_t)stream);
+  { ProfScope ps(p, VN_K_WF, (hipStream_t)stream); launch_decode<MODE_WF>(p, a, (hipStream_t)stream); }
   VN_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -863,11 +864,11 @@ extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* H
   vaenmf_rng rng = {VAENMF_RNG_DEVICE, 0, nullptr, nullptr};
   for (int it = 0; it < niter; ++it) {                  // EM.run, mcem.py:159-165
     rng.call = (uint32_t)it;
-    if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, B1, Zs, Rcap, nsE, biE, var_rw, &rng, nullptr, stream)) return e;
+    if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, 1, B1, Zs, Rcap, nsE, biE, var_rw, &rng, nullptr, stream)) return e;
     if (int e = vaenmf_m_step(p, X2, W, Ht, g, Zs, Rcap, nsE, B1, p->cost_frames, stream)) return e;
     if (cost) if (int e = vn_launch_cost_reduce(p, p->cost_frames, nsE, cost, niter, it, st)) return e;
   }
   rng.call = (uint32_t)niter;                           // compute_WF(sample=True), mcem.py:173
-  if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, B1, Zs, Rcap, nsWF, biWF, var_rw, &rng, nullptr, stream)) return e;
+  if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, 0, B1, Zs, Rcap, nsWF, biWF, var_rw, &rng, nullptr, stream)) return e;
   return vaenmf_wiener(p, X2, W, Ht, g, Zs, Rcap, nsWF, B1, X, S_hat, N_hat, nullptr, nullptr, stream);
 }

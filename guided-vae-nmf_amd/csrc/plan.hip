@@ -86,6 +86,8 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   p->Dy = 0;
   p->have_weights = false;
   p->n_utt = p->NT = p->n_tiles = 0;
+  p->prof_on = false;
+  p->prof_used = 0;
   int dev = 0;
   hipDeviceProp_t prop;
   VN_CHECK_HIP(hipGetDevice(&dev));
@@ -122,6 +124,7 @@ extern "C" void vaenmf_plan_destroy(vaenmf_plan* p) {
                   p->d_tile_cnt, p->d_frame_utt, p->d_frame_loc, p->d_utt_seed, p->A1, p->P, p->normW, p->cost_frames};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
+  for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
   delete p;
 }
 
@@ -210,4 +213,36 @@ extern "C" int vaenmf_layer1_bias(vaenmf_plan* p, const float* y, int32_t Dy, fl
   VN_REQUIRE(p->have_weights && p->NT > 0, "plan needs weights and a bound batch");
   VN_REQUIRE(Dy == p->Dy && Dy > 0, "label width %d does not match decoder input (L+%d)", Dy, p->Dy);
   return vaenmf_dense(y, p->NT, Dy, Dy, p->w1y, p->b1, HID, VAENMF_ACT_NONE, B1, HID, stream);
+}
+
+// Per-kernel timing: HIP events recorded on the launch stream around every hot-path
+// launch (kinds: 0 mh_chain, 1 decode+W-stats, 2 W update, 3 decode+H/g/cost, 4 decode+Wiener).
+extern "C" int vaenmf_profile_enable(vaenmf_plan* p, int32_t max_launches) {
+  VN_REQUIRE(p, "null plan");
+  for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
+  p->prof_ev.clear();
+  p->prof_kind.clear();
+  p->prof_used = 0;
+  p->prof_on = max_launches > 0;
+  for (int i = 0; i < 2 * max_launches; ++i) {
+    hipEvent_t e;
+    VN_CHECK_HIP(hipEventCreate(&e));
+    p->prof_ev.push_back(e);
+  }
+  p->prof_kind.assign(max_launches > 0 ? max_launches : 0, 0);
+  return 0;
+}
+// Synchronises, then ms[k] = summed device time of kind k, counts[k] = launches; resets.
+extern "C" int vaenmf_profile_read(vaenmf_plan* p, double* ms, int64_t* counts) {
+  VN_REQUIRE(p && ms && counts, "null argument");
+  for (int k = 0; k < VN_K_NKINDS; ++k) { ms[k] = 0.0; counts[k] = 0; }
+  for (size_t i = 0; i + 1 < p->prof_used; i += 2) {
+    VN_CHECK_HIP(hipEventSynchronize(p->prof_ev[i + 1]));
+    float t = 0.f;
+    VN_CHECK_HIP(hipEventElapsedTime(&t, p->prof_ev[i], p->prof_ev[i + 1]));
+    ms[p->prof_kind[i / 2]] += t;
+    counts[p->prof_kind[i / 2]] += 1;
+  }
+  p->prof_used = 0;
+  return 0;
 }

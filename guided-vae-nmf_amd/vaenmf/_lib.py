@@ -31,7 +31,7 @@ SIGNATURES = {
     "vaenmf_set_decoder_weights": (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
     "vaenmf_bind_batch": (_I, [_P, _I, _P, _P]),
     "vaenmf_layer1_bias": (_I, [_P, _P, _I, _P, _P]),
-    "vaenmf_mh_chain": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, C.POINTER(Rng), _P, _P]),
+    "vaenmf_mh_chain": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _F, C.POINTER(Rng), _P, _P]),
     "vaenmf_rng_fill": (_I, [_P, C.c_uint32, _I, _P, _P, _P]),
     "vaenmf_decode": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "vaenmf_m_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
@@ -43,6 +43,8 @@ SIGNATURES = {
     "vaenmf_stft_batch": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "vaenmf_istft_batch": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     "vaenmf_gram3_batch": (_I, [_P, _P, _P, _I, _P, _P, _P]),
+    "vaenmf_profile_enable": (_I, [_P, _I]),
+    "vaenmf_profile_read": (_I, [_P, _P, _P]),
 }
 
 _lib = None

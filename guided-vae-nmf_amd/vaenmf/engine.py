@@ -153,11 +153,11 @@ class BatchEngine:
         check(lib().vaenmf_layer1_bias(self._plan, _ptr(y), self.Dy, _ptr(self.B1), _stream()))
 
     # ------------------------------------------------------------------ hot path
-    def mh_chain(self, nsamples, burnin, var_rw, call=0, eps=None, u=None, want_acc=False):
+    def mh_chain(self, nsamples, burnin, var_rw, call=0, eps=None, u=None, want_acc=False, update_Z=True):
         rng = _lib.Rng(_lib.RNG_DEVICE if eps is None else _lib.RNG_REPLAY, int(call), _ptr(eps), _ptr(u))
         acc = torch.empty(nsamples + burnin, self.NT, device=self.device, dtype=torch.float32) if want_acc else None
         check(lib().vaenmf_mh_chain(self._plan, _ptr(self.X2), _ptr(self.W), _ptr(self.Ht), _ptr(self.g), _ptr(self.Z),
-                                    _ptr(self.B1), _ptr(self.Zs), self.Rcap, int(nsamples), int(burnin), float(var_rw),
+                                    int(bool(update_Z)), _ptr(self.B1), _ptr(self.Zs), self.Rcap, int(nsamples), int(burnin), float(var_rw),
                                     C.byref(rng), _ptr(acc), _stream()))
         return acc
 

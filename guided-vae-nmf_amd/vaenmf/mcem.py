@@ -129,7 +129,7 @@ class _MCEM:
         self.compute_Vs_scaled()
         self.compute_Vx()
 
-    def _chain(self, nsamples, burnin, want_acc=False):
+    def _chain(self, nsamples, burnin, want_acc=False, update_Z=True):
         eng, N = self._eng, self._N
         eps = u = None
         if self.rng == "replay":
@@ -140,7 +140,8 @@ class _MCEM:
                 e[m] = torch.randn(LAT, N).T
                 uu[m] = torch.rand(N)
             eps, u = e.to(self.device), uu.to(self.device)
-        acc = eng.mh_chain(nsamples, burnin, self.var_RW, call=self._call, eps=eps, u=u, want_acc=want_acc)
+        acc = eng.mh_chain(nsamples, burnin, self.var_RW, call=self._call, eps=eps, u=u, want_acc=want_acc,
+                           update_Z=update_Z)
         self._call += 1
         return acc
 
@@ -158,7 +159,7 @@ class _MCEM:
     def compute_WF(self, sample=False):
         if sample:
             ns, bi = self.wf_counts()
-            self._chain(ns, bi)
+            self._chain(ns, bi, update_Z=False)                                # mcem.py:477-478: self.Z untouched
             self._R = ns
         S, Nn, WFs, WFn = self._eng.wiener(self._R, want_masks=True)
         self._S_dev, self._N_dev = S, Nn

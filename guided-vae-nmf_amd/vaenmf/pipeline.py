@@ -1,0 +1,71 @@
+"""Batched reconstruct pipeline (the build's counterpart of scripts/evaluate_M1.py:
+111-177 process_utt/process_sublist, many utterances per launch): device-resident
+waveforms -> STFT -> |X|^2 -> encoder -> fused EM (MH E-steps, multiplicative-update
+M-steps) -> Wiener filter -> iSTFT -> enhanced waveforms, plus utterance sharding over
+ranks (np.array_split, evaluate_M1.py:203-206) and the final metrics all-reduce."""
+import numpy as np
+import torch
+
+from . import stft as vstft
+from . import metrics as vmet
+from .engine import BatchEngine, decoder_params_from_state
+from .mcem import _encoder_params
+
+
+def shard(items, world_size, rank):
+    """Contiguous split of the sorted list over ranks, exactly np.array_split
+    (scripts/evaluate_M1.py:203)."""
+    return list(np.array_split(np.asarray(items, dtype=object), world_size)[rank])
+
+
+class Reconstructor:
+    def __init__(self, state_dict, x_dim, nmf_rank, niter=100, nsamples_E_step=10, burnin_E_step=30,
+                 nsamples_WF=25, burnin_WF=75, var_RW=0.01, model="M1", reference_compat=True,
+                 fs=16000, wlen_sec=64e-3, hop_percent=0.25, eps=1e-8, precision="bf16x3", device="cuda:0",
+                 max_frames=1 << 16, max_utts=128):
+        sd = {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)) for k, v in state_dict.items()}
+        self.enc = _encoder_params(sd)
+        self.F, self.K, self.niter, self.var_RW, self.eps = int(x_dim), int(nmf_rank), int(niter), var_RW, eps
+        self.fs, self.wlen_sec, self.hop_percent = fs, wlen_sec, hop_percent
+        if model == "M1" and reference_compat:          # mcem.py:461-462 / :477-478 positional shift
+            self.nsE, self.biE, self.nsW, self.biW = burnin_E_step, 30, burnin_WF, 30
+        else:
+            self.nsE, self.biE, self.nsW, self.biW = nsamples_E_step, burnin_E_step, nsamples_WF, burnin_WF
+        self.device = torch.device(device)
+        self.eng = BatchEngine(self.F, self.K, decoder_params_from_state(sd), precision=precision, device=device,
+                               max_frames=max_frames, max_utts=max_utts)
+        self.model = model
+
+    def enhance(self, wav, sample_counts, seeds=None, init_seed=0, y=None):
+        """wav: device float32 [sum T].  Returns (s_hat, n_hat) device float32 [sum T], cost [U,niter] (device)."""
+        eng = self.eng
+        X, fc = vstft.stft_batch(wav, sample_counts, self.fs, self.wlen_sec, self.hop_percent, Fs=eng.Fs, device=self.device)
+        eng.bind(fc, Rcap=max(self.nsE, self.nsW), seeds=seeds)
+        eng.set_spectrogram(X)
+        # W = max(rand(F,K), eps), H = max(rand(K,N), eps), g = 1 (mcem.py:42-44), device generator
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(int(init_seed))
+        eng.W.zero_()
+        eng.W[:, :self.F, :self.K] = torch.rand(eng.U, self.F, self.K, device=self.device, generator=gen).clamp_min(self.eps)
+        eng.Ht.zero_()
+        eng.Ht[:, :self.K] = torch.rand(eng.NT, self.K, device=self.device, generator=gen).clamp_min(self.eps)
+        eng.g.fill_(1.0)
+        if y is not None:
+            eng.set_labels(y)
+        eng.encode(self.enc, y)
+        cost, S, N = eng.run(self.niter, self.nsE, self.biE, self.nsW, self.biW, self.var_RW)
+        nfft, hop = vstft.frame_geometry(sample_counts[0], self.fs, self.wlen_sec, self.hop_percent)[:2]
+        s_hat = vstft.istft_batch(S, fc, sample_counts, nfft, hop, device=self.device)
+        n_hat = vstft.istft_batch(N, fc, sample_counts, nfft, hop, device=self.device)
+        self.frame_counts = fc
+        return s_hat, n_hat, cost
+
+
+def allreduce_stats(stats, device):
+    """Sum the metric sufficient statistics over ranks (RCCL when the process group is
+    'nccl'); the only collective of the whole job."""
+    import torch.distributed as dist
+    t = torch.as_tensor(stats, dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()

@@ -99,11 +99,12 @@ int vaenmf_layer1_bias(vaenmf_plan* p, const float* y, int32_t Dy, float* B1, vo
 
 /* Metropolis-Hastings chain of one E-step / Wiener phase -- replaces
  * MCEM_M1.sample_posterior (mcem.py:371-441) and MCEM_M2.sample_posterior (:218-294):
- * nsamples+burnin random-walk steps per frame, samples after burn-in to Zs[:, 0..nsamples-1, :],
- * Z overwritten with the last draw (mcem.py:466).  acc_out (DEV [S][NT], may be NULL)
- * receives the log-acceptance of every step (mcem.py:415-417) for parity tests. */
+ * nsamples+burnin random-walk steps per frame, samples after burn-in to Zs[:, 0..nsamples-1, :].
+ * update_Z != 0: Z is overwritten with the last draw, as E_step does (mcem.py:466);
+ * update_Z == 0: Z is only read, as compute_WF does (mcem.py:477-478).  acc_out (DEV
+ * [S][NT], may be NULL) receives the log-acceptance of every step (mcem.py:415-417). */
 int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, const float* Ht, const float* g,
-                    float* Z, const float* B1, float* Zs, int32_t Rcap,
+                    float* Z, int32_t update_Z, const float* B1, float* Zs, int32_t Rcap,
                     int32_t nsamples, int32_t burnin, float var_rw,
                     const vaenmf_rng* rng, float* acc_out, void* stream);
 
@@ -183,6 +184,14 @@ int vaenmf_istft_batch(const float* S, int32_t n_utt, int32_t n_frames_total,
  * {<sh,sh>, <sh,s>, <sh,n>, <s,s>, <s,n>, <n,n>}; sample_offsets DEV int64 [n_utt+1]. */
 int vaenmf_gram3_batch(const float* s_hat, const float* s, const float* n, int32_t n_utt,
                        const int64_t* sample_offsets, double* out, void* stream);
+
+/* Per-kernel device timing with HIP events recorded on the launch stream around every
+ * hot-path launch (kinds: 0 mh_chain, 1 decode+W-statistics, 2 W update, 3 decode+H/g/cost,
+ * 4 decode+Wiener).  enable(max_launches>0) pre-creates the events (no allocation at
+ * launch time); read() synchronises, returns summed milliseconds and launch counts per
+ * kind (arrays of 5) and resets. */
+int vaenmf_profile_enable(vaenmf_plan* p, int32_t max_launches);
+int vaenmf_profile_read(vaenmf_plan* p, double* ms, int64_t* counts);
 
 #ifdef __cplusplus
 }

@@ -137,7 +137,7 @@ def test_first_em_iteration(name, model):
     # oracle chain on the same draws
     rng.pos = pos0
     Zs_ref = o.sample_posterior(o.Z, ns, bi)
-    assert np.max(np.abs(eng.Zs[:, :ns].cpu().numpy() - Zs_ref)) < 1e-6
+    assert np.max(np.abs(eng.Zs[:, :ns].cpu().numpy() - Zs_ref)) < 5e-6   # fma contraction of z + sd*eps
     assert np.max(np.abs(eng.Z.cpu().numpy().T - z["E1_Z"])) < 1e-5
     Vs = eng.decode(ns).cpu().numpy()[:, :, :F]                    # [N,R,F]
     assert rel_err(np.moveaxis(Vs, 0, -1), z["E1_Vs"]) < 2e-4
@@ -171,7 +171,7 @@ def test_full_run_replay(name, model):
         eng.m_step(ns)
         cost[it] = eng.cost_from_frames(ns)[0]
     eps, u = replay_buffers(rng, nw + bw, N, 32, eng.device)
-    eng.mh_chain(nw, bw, 0.01, eps=eps, u=u)
+    eng.mh_chain(nw, bw, 0.01, eps=eps, u=u, update_Z=False)
     S, Nn, WFs, WFn = eng.wiener(nw, want_masks=True)
     assert rng.pos == len(rng.draws)
     assert np.max(np.abs(cost - z["cost"]) / np.abs(z["cost"])) < 2e-4
@@ -285,7 +285,7 @@ def test_fused_run_equals_stepwise_and_batches_are_independent():
         eng2.mh_chain(nsE, biE, 0.01, call=it)
         eng2.m_step(nsE)
         c2[:, it] = eng2.cost_from_frames(nsE)
-    eng2.mh_chain(nsW, biW, 0.01, call=niter)
+    eng2.mh_chain(nsW, biW, 0.01, call=niter, update_Z=False)
     S2, N2, _, _ = eng2.wiener(nsW)
     assert torch.equal(S, S2) and torch.equal(N, N2)
     assert np.max(np.abs(c2 - cost) / np.abs(cost)) < 1e-12
