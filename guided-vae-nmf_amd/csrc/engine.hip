@@ -22,20 +22,44 @@ namespace {
 constexpr int NK_H = HID / 32;     // k-steps over a hidden layer (4)
 constexpr int NT_H = HID / 16;     // feature tiles of a hidden layer (8)
 
-struct DecW {                      // decoder weights (device), fragment order
+struct DecW {                      // decoder weights (device), fragment order [tile][kstep][part][lane][8]
   const __bf16 *w1f, *w2f, *w3f;
   const float *b1, *b2, *b3;
   int NT3;                         // feature tiles in the last layer
   int F;
 };
 
-__device__ __forceinline__ bf16x8 ldw(const __bf16* base, int tile, int nk, int s, int part, int lane) {
-  return *reinterpret_cast<const bf16x8*>(base + ((((size_t)tile * nk + s) * 2 + part) * 64 + lane) * 8);
-}
+// ---- LDS carve (one dynamic array; every offset a multiple of 16) ------------------
+// act1/act2: activation images [col group][k-step][part][lane][8 bf16]   (2 col groups)
+// w1/w2(/w3): weight fragments, PARTS = 2 (hi,lo) in bf16x3 mode, 1 in bf16 mode
+template <bool SPLIT>
+struct LdsMap {
+  static constexpr int PARTS = SPLIT ? 2 : 1;
+  static constexpr int ACT = 2 * NK_H * 2 * 1024;
+  static constexpr int W1B = NT_H * 1 * PARTS * 1024;
+  static constexpr int W2B = NT_H * NK_H * PARTS * 1024;
+  static constexpr int act1 = 0;
+  static constexpr int act2 = act1 + ACT;
+  static constexpr int w1 = act2 + ACT;
+  static constexpr int w2 = w1 + W1B;
+  static constexpr int b2 = w2 + W2B;              // float[HID]
+  static constexpr int b3 = b2 + HID * 4;          // float[Fs_max = 640]
+  static constexpr int common_end = b3 + 640 * 4;
+  static __host__ __device__ constexpr int w3_bytes(int NT3) { return NT3 * NK_H * PARTS * 1024; }
+};
 
-// LDS activation image: [col group][k-step][part][lane][8 bf16]  (1 KB blocks)
-__device__ __forceinline__ int act_off(int cg, int s, int part, int lane) {
-  return (((cg * NK_H + s) * 2 + part) * 64 + lane) * 16;   // bytes
+__device__ __forceinline__ int act_off(int cg, int s, int part) { return ((cg * NK_H + s) * 2 + part) * 1024; }
+
+// copy fragment blocks global -> LDS (PARTS==1 keeps the hi block only)
+template <int PARTS>
+__device__ __forceinline__ void stage_weights(char* dst, const __bf16* src, int nblocks /* tile*kstep */) {
+  const int nthr = blockDim.x;
+  for (int e = threadIdx.x; e < nblocks * PARTS * 64; e += nthr) {       // 16-byte chunks
+    const int chunk = e & 63, blk = e >> 6;
+    const int b = blk / PARTS, part = blk - b * PARTS;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(src) + ((size_t)(b * 2 + part) * 64 + chunk) * 16);
+    *reinterpret_cast<f32x4*>(dst + (size_t)e * 16) = v;
+  }
 }
 
 template <bool SPLIT>
@@ -57,123 +81,150 @@ __device__ __forceinline__ f32x4 mma3_flip(const bf16x8 ahi, const bf16x8 alo, c
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, whi, acc, 0, 0, 0);
 }
 
+template <bool SPLIT>
 __device__ __forceinline__ void split8(const float (&z)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     __bf16 h = (__bf16)z[j];
     hi[j] = h;
-    lo[j] = (__bf16)(z[j] - (float)h);
+    lo[j] = SPLIT ? (__bf16)(z[j] - (float)h) : (__bf16)0.f;
   }
 }
 
 // tanh + split + store one accumulator tile (feature tile `tile`) into the LDS image
-__device__ __forceinline__ void store_act(char* act, int cg, int tile, int lane, f32x4 acc) {
+template <bool SPLIT>
+__device__ __forceinline__ void store_act(char* act, int lane16, int cg, int tile, f32x4 acc) {
   f32x4 h;
 #pragma unroll
   for (int t = 0; t < 4; ++t) h[t] = fast_tanh(acc[t]);
-  bf16x4 hi, lo;
-  split4(h, hi, lo);
   const int s = tile >> 1, e = tile & 1;
-  *reinterpret_cast<bf16x4*>(act + act_off(cg, s, 0, lane) + e * 8) = hi;
-  *reinterpret_cast<bf16x4*>(act + act_off(cg, s, 1, lane) + e * 8) = lo;
+  bf16x4 hi, lo;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    __bf16 x = (__bf16)h[t];
+    hi[t] = x;
+    lo[t] = (__bf16)(h[t] - (float)x);
+  }
+  *reinterpret_cast<bf16x4*>(act + act_off(cg, s, 0) + lane16 + e * 8) = hi;
+  if (SPLIT) *reinterpret_cast<bf16x4*>(act + act_off(cg, s, 1) + lane16 + e * 8) = lo;
 }
 
-// Hidden layers 1 and 2 for NCG column groups.  zhi/zlo: layer-1 B fragments (the
-// latent rows); bias1[ti][cg]: accumulator init of layer 1 (per-column bias for M2).
-// Leaves tanh(layer 2) in act2 (LDS, fragment order).  Two workgroup barriers.
-template <int NW, int NCG, bool SPLIT>
-__device__ __forceinline__ void hidden_layers(const DecW& dw, char* act1, char* act2, int w, int lane,
-                                              const bf16x8 (&zhi)[NCG], const bf16x8 (&zlo)[NCG],
-                                              const f32x4 (&bias1)[NT_H / NW][NCG], const f32x4 (&bias2)[NT_H / NW]) {
-  constexpr int TPW = NT_H / NW;
-  // ---- layer 1: K = LAT = 32 -> one k-step
-#pragma unroll
-  for (int ti = 0; ti < TPW; ++ti) {
-    const int tile = w + NW * ti;
-    const bf16x8 whi = ldw(dw.w1f, tile, 1, 0, 0, lane);
-    const bf16x8 wlo = ldw(dw.w1f, tile, 1, 0, 1, lane);
-#pragma unroll
-    for (int cg = 0; cg < NCG; ++cg) {
-      f32x4 acc = mma3<SPLIT>(whi, wlo, zhi[cg], zlo[cg], bias1[ti][cg]);
-      store_act(act1, cg, tile, lane, acc);
+// Everything a wave needs to run the decoder: LDS pointers + its (uniform) wave index.
+template <int NW, bool SPLIT, bool W3LDS>
+struct Dec {
+  using M = LdsMap<SPLIT>;
+  static constexpr int TPW = NT_H / NW;
+  char* lds;
+  const char* w3g;      // global W3 fragments of this wave's first tile (uniform pointer)   [!W3LDS]
+  const char* w3l;      // LDS W3 fragments                                                  [W3LDS]
+  int w, NT3;
+  unsigned lane16;
+
+  __device__ __forceinline__ void lds_w(int base, int tile, int nk, int s, bf16x8& hi, bf16x8& lo) const {
+    const char* p = lds + base + ((tile * nk + s) * M::PARTS) * 1024 + lane16;
+    hi = *reinterpret_cast<const bf16x8*>(p);
+    if (SPLIT) lo = *reinterpret_cast<const bf16x8*>(p + 1024); else lo = hi;
+  }
+  __device__ __forceinline__ void w3_frag(int i, int s, bf16x8& hi, bf16x8& lo) const {
+    if (W3LDS) {
+      const char* p = w3l + (((w + NW * i) * NK_H + s) * M::PARTS) * 1024 + lane16;
+      hi = *reinterpret_cast<const bf16x8*>(p);
+      if (SPLIT) lo = *reinterpret_cast<const bf16x8*>(p + 1024); else lo = hi;
+    } else {
+      const char* p = w3g + (size_t)((i * NW * NK_H + s) * 2) * 1024 + lane16;
+      hi = *reinterpret_cast<const bf16x8*>(p);
+      if (SPLIT) lo = *reinterpret_cast<const bf16x8*>(p + 1024); else lo = hi;
     }
   }
-  __syncthreads();
-  // ---- layer 2
-  f32x4 acc2[TPW][NCG];
-#pragma unroll
-  for (int ti = 0; ti < TPW; ++ti)
-#pragma unroll
-    for (int cg = 0; cg < NCG; ++cg) acc2[ti][cg] = bias2[ti];
-#pragma unroll
-  for (int s = 0; s < NK_H; ++s) {
-    bf16x8 ahi[NCG], alo[NCG];
-#pragma unroll
-    for (int cg = 0; cg < NCG; ++cg) {
-      ahi[cg] = *reinterpret_cast<const bf16x8*>(act1 + act_off(cg, s, 0, lane));
-      alo[cg] = *reinterpret_cast<const bf16x8*>(act1 + act_off(cg, s, 1, lane));
-    }
+  __device__ __forceinline__ void act_frag(int which, int cg, int s, bf16x8& hi, bf16x8& lo) const {
+    const char* p = lds + (which ? M::act2 : M::act1) + act_off(cg, s, 0) + lane16;
+    hi = *reinterpret_cast<const bf16x8*>(p);
+    if (SPLIT) lo = *reinterpret_cast<const bf16x8*>(p + 1024); else lo = hi;
+  }
+
+  // Hidden layers 1 and 2 for two column groups.  zhi/zlo: layer-1 B fragments (latent rows);
+  // bias1[ti][cg]: accumulator init of layer 1.  Leaves tanh(layer 2) in act2.  Two barriers.
+  __device__ __forceinline__ void hidden(const bf16x8 (&zhi)[2], const bf16x8 (&zlo)[2], const f32x4 (&bias1)[TPW][2]) const {
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
       const int tile = w + NW * ti;
-      const bf16x8 whi = ldw(dw.w2f, tile, NK_H, s, 0, lane);
-      const bf16x8 wlo = ldw(dw.w2f, tile, NK_H, s, 1, lane);
+      bf16x8 whi, wlo;
+      lds_w(M::w1, tile, 1, 0, whi, wlo);
 #pragma unroll
-      for (int cg = 0; cg < NCG; ++cg) acc2[ti][cg] = mma3<SPLIT>(whi, wlo, ahi[cg], alo[cg], acc2[ti][cg]);
+      for (int cg = 0; cg < 2; ++cg)
+        store_act<SPLIT>(lds + M::act1, lane16, cg, tile, mma3<SPLIT>(whi, wlo, zhi[cg], zlo[cg], bias1[ti][cg]));
     }
+    __syncthreads();
+    f32x4 acc2[TPW][2];
+    const float* b2 = reinterpret_cast<const float*>(lds + M::b2);
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + 16 * (w + NW * ti) + (lane16 >> 8) * 4);   // 4*q
+      acc2[ti][0] = bv; acc2[ti][1] = bv;
+    }
+#pragma unroll
+    for (int s = 0; s < NK_H; ++s) {
+      bf16x8 ahi[2], alo[2];
+      act_frag(0, 0, s, ahi[0], alo[0]);
+      act_frag(0, 1, s, ahi[1], alo[1]);
+#pragma unroll
+      for (int ti = 0; ti < TPW; ++ti) {
+        bf16x8 whi, wlo;
+        lds_w(M::w2, w + NW * ti, NK_H, s, whi, wlo);
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) acc2[ti][cg] = mma3<SPLIT>(whi, wlo, ahi[cg], alo[cg], acc2[ti][cg]);
+      }
+    }
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg) store_act<SPLIT>(lds + M::act2, lane16, cg, w + NW * ti, acc2[ti][cg]);
+    __syncthreads();
   }
-#pragma unroll
-  for (int ti = 0; ti < TPW; ++ti)
-#pragma unroll
-    for (int cg = 0; cg < NCG; ++cg) store_act(act2, cg, w + NW * ti, lane, acc2[ti][cg]);
-  __syncthreads();
-}
 
-// Last layer, orientation [features x columns]: acc[i][cg] rows = bins 16*tile+4q+t.
-template <int NW, int NCG, bool SPLIT>
-__device__ __forceinline__ void out_layer(const DecW& dw, const char* act2, int w, int lane, f32x4 (&acc)[MAXT][NCG]) {
+  // Last layer.  FLIP=false: acc[i][cg] rows = bins 16*tile+4q+t, cols = columns (frames);
+  //              FLIP=true : acc[i][cg] rows = columns (samples) 4q+t, col = bin 16*tile+c.
+  template <bool FLIP>
+  __device__ __forceinline__ void out_layer(f32x4 (&acc)[MAXT][2]) const {
 #pragma unroll
-  for (int s = 0; s < NK_H; ++s) {
-    bf16x8 ahi[NCG], alo[NCG];
+    for (int s = 0; s < NK_H; ++s) {
+      bf16x8 ahi[2], alo[2];
+      act_frag(1, 0, s, ahi[0], alo[0]);
+      act_frag(1, 1, s, ahi[1], alo[1]);
 #pragma unroll
-    for (int cg = 0; cg < NCG; ++cg) {
-      ahi[cg] = *reinterpret_cast<const bf16x8*>(act2 + act_off(cg, s, 0, lane));
-      alo[cg] = *reinterpret_cast<const bf16x8*>(act2 + act_off(cg, s, 1, lane));
-    }
+      for (int i = 0; i < MAXT; ++i) {
+        if (w + NW * i < NT3) {   // wave-uniform (w is an SGPR value)
+          bf16x8 whi, wlo;
+          w3_frag(i, s, whi, wlo);
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      const int tile = w + NW * i;
-      if (tile < dw.NT3) {   // wave-uniform
-        const bf16x8 whi = ldw(dw.w3f, tile, NK_H, s, 0, lane);
-        const bf16x8 wlo = ldw(dw.w3f, tile, NK_H, s, 1, lane);
-#pragma unroll
-        for (int cg = 0; cg < NCG; ++cg) acc[i][cg] = mma3<SPLIT>(whi, wlo, ahi[cg], alo[cg], acc[i][cg]);
+          for (int cg = 0; cg < 2; ++cg)
+            acc[i][cg] = FLIP ? mma3_flip<SPLIT>(ahi[cg], alo[cg], whi, wlo, acc[i][cg])
+                              : mma3<SPLIT>(whi, wlo, ahi[cg], alo[cg], acc[i][cg]);
+        }
       }
     }
   }
-}
-// Last layer, orientation [columns x features]: acc[i][cg] rows = samples 4q+t, col = bin 16*tile+c.
-template <int NW, int NCG, bool SPLIT>
-__device__ __forceinline__ void out_layer_flip(const DecW& dw, const char* act2, int w, int lane, f32x4 (&acc)[MAXT][NCG]) {
-#pragma unroll
-  for (int s = 0; s < NK_H; ++s) {
-    bf16x8 ahi[NCG], alo[NCG];
-#pragma unroll
-    for (int cg = 0; cg < NCG; ++cg) {
-      ahi[cg] = *reinterpret_cast<const bf16x8*>(act2 + act_off(cg, s, 0, lane));
-      alo[cg] = *reinterpret_cast<const bf16x8*>(act2 + act_off(cg, s, 1, lane));
-    }
-#pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      const int tile = w + NW * i;
-      if (tile < dw.NT3) {
-        const bf16x8 whi = ldw(dw.w3f, tile, NK_H, s, 0, lane);
-        const bf16x8 wlo = ldw(dw.w3f, tile, NK_H, s, 1, lane);
-#pragma unroll
-        for (int cg = 0; cg < NCG; ++cg) acc[i][cg] = mma3_flip<SPLIT>(ahi[cg], alo[cg], whi, wlo, acc[i][cg]);
-      }
-    }
-  }
+};
+
+// workgroup prologue shared by both kernels: stage W1/W2 (and W3 when it fits), b2, b3 into LDS
+template <int NW, bool SPLIT, bool W3LDS>
+__device__ __forceinline__ Dec<NW, SPLIT, W3LDS> dec_setup(char* smem, const DecW& dw, int w3_lds_off, int Fs) {
+  using M = LdsMap<SPLIT>;
+  Dec<NW, SPLIT, W3LDS> d;
+  d.lds = smem;
+  d.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  d.lane16 = (threadIdx.x & 63) * 16;
+  d.NT3 = dw.NT3;
+  d.w3g = reinterpret_cast<const char*>(dw.w3f) + (size_t)d.w * NK_H * 2 * 1024;
+  d.w3l = smem + (W3LDS ? w3_lds_off : 0);
+  stage_weights<M::PARTS>(smem + M::w1, dw.w1f, NT_H);
+  stage_weights<M::PARTS>(smem + M::w2, dw.w2f, NT_H * NK_H);
+  if (W3LDS) stage_weights<M::PARTS>(smem + w3_lds_off, dw.w3f, dw.NT3 * NK_H);
+  float* b2 = reinterpret_cast<float*>(smem + M::b2);
+  float* b3 = reinterpret_cast<float*>(smem + M::b3);
+  for (int i = threadIdx.x; i < HID; i += blockDim.x) b2[i] = dw.b2[i];
+  for (int i = threadIdx.x; i < Fs; i += blockDim.x) b3[i] = dw.b3[i];
+  return d;
 }
 
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
@@ -189,29 +240,38 @@ struct ChainArgs {
   const uint64_t* utt_seed;
   const float *eps, *u;      // replay buffers or null
   int Fs, Kp, NT, Rcap, nsamples, burnin, rng_mode, update_Z;
+  int w3_lds_off;            // LDS offset of the W3 fragments, or -1 (streamed from L2)
   uint32_t call;
   float sd;                  // sqrt(var_RW)
 };
 
-constexpr int ACT_BYTES_CHAIN = 2 * NK_H * 2 * 1024;   // 2 column groups
-
-struct ChainLds {
-  char act1[ACT_BYTES_CHAIN];
-  char act2[ACT_BYTES_CHAIN];
+// chain-specific LDS after LdsMap::common_end
+struct ChainX {
+  float b1tab[FRAMES_PER_TILE][HID];      // layer-1 accumulator init per frame (b1 or B1[n])
   float eps[2][FRAMES_PER_TILE][LAT];
   float u[2][FRAMES_PER_TILE];
   double epart[2][8][FRAMES_PER_TILE];
 };
 
-template <int NW, bool SPLIT>
+template <int NW, bool SPLIT, bool W3LDS>
 __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  ChainLds& L = *reinterpret_cast<ChainLds*>(smem);
+  using M = LdsMap<SPLIT>;
   constexpr int TPW = NT_H / NW;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4, c = lane & 15;
+  ChainX& L = *reinterpret_cast<ChainX*>(smem + M::common_end);
+  const DecW& dw = a.dw;
+  const Dec<NW, SPLIT, W3LDS> d = dec_setup<NW, SPLIT, W3LDS>(smem, dw, a.w3_lds_off, a.Fs);
+  const int lane = threadIdx.x & 63, w = d.w, q = lane >> 4, c = lane & 15;
   const int tile = blockIdx.x;
   const int utt = a.tile_utt[tile], n0 = a.tile_n0[tile], cnt = a.tile_cnt[tile];
-  const DecW& dw = a.dw;
+
+  // layer-1 bias table (per frame for M2: b1 + W1y y_n, folded by vaenmf_layer1_bias)
+  for (int e = threadIdx.x; e < FRAMES_PER_TILE * HID / 4; e += blockDim.x) {
+    const int fr = e / (HID / 4), h4 = e - fr * (HID / 4);
+    const int nr = n0 + (fr < cnt ? fr : cnt - 1);
+    reinterpret_cast<f32x4*>(&L.b1tab[fr][0])[h4] =
+        a.B1 ? reinterpret_cast<const f32x4*>(a.B1 + (size_t)nr * HID)[h4] : reinterpret_cast<const f32x4*>(dw.b1)[h4];
+  }
 
   // ---- frames of this lane (one per column group)
   int nrow[2];
@@ -225,13 +285,12 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
     gn[fg] = a.g[nrow[fg]];
   }
   // ---- per-(bin,frame) constants in accumulator layout: X2 and Vb = W H (mcem.py:81-82)
-  f32x4 x2[MAXT][2], vb[MAXT][2], b3v[MAXT];
+  f32x4 x2[MAXT][2], vb[MAXT][2];
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
     const int t16 = w + NW * i;
     const int f0 = 16 * t16 + 4 * q;
     const bool tv = t16 < dw.NT3;
-    b3v[i] = tv ? *reinterpret_cast<const f32x4*>(dw.b3 + f0) : f32x4{0, 0, 0, 0};
 #pragma unroll
     for (int fg = 0; fg < 2; ++fg) {
       x2[i][fg] = tv ? *reinterpret_cast<const f32x4*>(a.X2 + (size_t)nrow[fg] * a.Fs + f0) : f32x4{0, 0, 0, 0};
@@ -248,17 +307,6 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
       }
       vb[i][fg] = v;
     }
-  }
-  // ---- layer biases
-  f32x4 bias1[TPW][2], bias2[TPW];
-#pragma unroll
-  for (int ti = 0; ti < TPW; ++ti) {
-    const int f0 = 16 * (w + NW * ti) + 4 * q;
-    bias2[ti] = *reinterpret_cast<const f32x4*>(dw.b2 + f0);
-#pragma unroll
-    for (int fg = 0; fg < 2; ++fg)
-      bias1[ti][fg] = a.B1 ? *reinterpret_cast<const f32x4*>(a.B1 + (size_t)nrow[fg] * HID + f0)
-                           : *reinterpret_cast<const f32x4*>(dw.b1 + f0);
   }
   // ---- current latent state, fragment order: latents 4q..4q+3 and 16+4q..16+4q+3
   float z[2][8];
@@ -295,18 +343,28 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
   };
 
   int ecount = 0;
+  const float* b3l = reinterpret_cast<const float*>(smem + M::b3);
   // E(z) = sum_f [log Vx + X2/Vx] per frame (fp64 accumulation: the reference sums the
   // per-bin DIFFERENCES of two states, mcem.py:415-416; summing each state separately
   // needs the extra bits to keep the same absolute accuracy).
   auto energy = [&](const float (&zz)[2][8], double (&E)[2]) {
     bf16x8 zhi[2], zlo[2];
-    split8(zz[0], zhi[0], zlo[0]);
-    split8(zz[1], zhi[1], zlo[1]);
-    hidden_layers<NW, 2, SPLIT>(dw, L.act1, L.act2, w, lane, zhi, zlo, bias1, bias2);
+    split8<SPLIT>(zz[0], zhi[0], zlo[0]);
+    split8<SPLIT>(zz[1], zhi[1], zlo[1]);
+    f32x4 bias1[TPW][2];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+      for (int fg = 0; fg < 2; ++fg)
+        bias1[ti][fg] = *reinterpret_cast<const f32x4*>(&L.b1tab[16 * fg + c][16 * (w + NW * ti) + 4 * q]);
+    d.hidden(zhi, zlo, bias1);
     f32x4 acc[MAXT][2];
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) { acc[i][0] = b3v[i]; acc[i][1] = b3v[i]; }
-    out_layer<NW, 2, SPLIT>(dw, L.act2, w, lane, acc);
+    for (int i = 0; i < MAXT; ++i) {
+      const f32x4 bv = (w + NW * i < dw.NT3) ? *reinterpret_cast<const f32x4*>(b3l + 16 * (w + NW * i) + 4 * q) : f32x4{0, 0, 0, 0};
+      acc[i][0] = bv; acc[i][1] = bv;
+    }
+    d.template out_layer<false>(acc);
     double e[2] = {0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
@@ -346,22 +404,25 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
 
   const int S = a.nsamples + a.burnin;
   draw(0);
-  double Ecur[2];
-  energy(z, Ecur);                                    // Vs_t = decoder(Z_t)  (mcem.py:392-400)
-  for (int m = 0; m < S; ++m) {
+  __syncthreads();                                    // staged weights, bias tables, first noise
+  double Ecur[2] = {0.0, 0.0};
+  // m = -1 evaluates the initial state, Vs_t = decoder(Z_t) (mcem.py:392-400); m >= 0 are the MH steps
+  for (int m = -1; m < S; ++m) {
     // ---- proposal  Z' = Z + sqrt(var) * randn   (mcem.py:407)
     float zp[2][8];
+    const float sd = m < 0 ? 0.f : a.sd;
+    const int eb = m & 1;
 #pragma unroll
     for (int fg = 0; fg < 2; ++fg) {
-      const f32x4 e0 = *reinterpret_cast<const f32x4*>(&L.eps[m & 1][16 * fg + c][4 * q]);
-      const f32x4 e1 = *reinterpret_cast<const f32x4*>(&L.eps[m & 1][16 * fg + c][16 + 4 * q]);
+      const f32x4 e0 = *reinterpret_cast<const f32x4*>(&L.eps[eb][16 * fg + c][4 * q]);
+      const f32x4 e1 = *reinterpret_cast<const f32x4*>(&L.eps[eb][16 * fg + c][16 + 4 * q]);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        zp[fg][t] = z[fg][t] + a.sd * e0[t];
-        zp[fg][4 + t] = z[fg][4 + t] + a.sd * e1[t];
+        zp[fg][t] = z[fg][t] + sd * e0[t];
+        zp[fg][4 + t] = z[fg][4 + t] + sd * e1[t];
       }
     }
-    if (m + 1 < S) draw(m + 1);
+    if (m >= 0 && m + 1 < S) draw(m + 1);
     double Ep[2];
     energy(zp, Ep);                                   // mcem.py:410-412
 #pragma unroll
@@ -372,9 +433,9 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
       pr += __shfl_xor(pr, 16, 64);
       pr += __shfl_xor(pr, 32, 64);
       const float accp = (float)(Ecur[fg] - Ep[fg]) + 0.5f * pr;
-      const float uu = L.u[m & 1][16 * fg + c];
-      const bool ok = logf(uu) < accp;                // mcem.py:420
-      if (a.acc_out && w == 0 && q == 0 && fvalid[fg]) a.acc_out[(size_t)m * a.NT + nrow[fg]] = accp;
+      const float uu = L.u[eb][16 * fg + c];
+      const bool ok = m < 0 || fast_log(uu) < accp;   // mcem.py:420
+      if (a.acc_out && m >= 0 && w == 0 && q == 0 && fvalid[fg]) a.acc_out[(size_t)m * a.NT + nrow[fg]] = accp;
       if (ok) {                                       // mcem.py:429-433
 #pragma unroll
         for (int j = 0; j < 8; ++j) z[fg][j] = zp[fg][j];
@@ -428,32 +489,29 @@ struct DecodeArgs {
   double* cost_frames;
   const int32_t* frame_utt;
   int Fs, K, NT, Rcap, R;
+  int w3_lds_off;
 };
 
-constexpr int ACT_BYTES_DEC = 2 * NK_H * 2 * 1024;   // 2 sample groups of 16
-
-struct DecodeLds {
-  char act1[ACT_BYTES_DEC];
-  char act2[ACT_BYTES_DEC];
+struct DecodeX {
   float redH[8][64];        // [wave][2*Kp]
   float redG[8][2];
   double redC[8];
 };
 
-template <int NW, bool SPLIT, int MODE, int KP>
+template <int NW, bool SPLIT, bool W3LDS, int MODE, int KP>
 __global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  DecodeLds& L = *reinterpret_cast<DecodeLds*>(smem);
+  using M = LdsMap<SPLIT>;
   constexpr int TPW = NT_H / NW;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4, c = lane & 15;
-  const DecW& dw = a.dw;
   constexpr int Kp = KP;
+  DecodeX& L = *reinterpret_cast<DecodeX*>(smem + M::common_end);
+  const DecW& dw = a.dw;
+  const Dec<NW, SPLIT, W3LDS> d = dec_setup<NW, SPLIT, W3LDS>(smem, dw, a.w3_lds_off, a.Fs);
+  const int lane = threadIdx.x & 63, w = d.w, q = lane >> 4, c = lane & 15;
   const int nch = (a.R + 31) / 32;
+  const float* b3l = reinterpret_cast<const float*>(smem + M::b3);
+  __syncthreads();
 
-  f32x4 bias2[TPW];
-#pragma unroll
-  for (int ti = 0; ti < TPW; ++ti) bias2[ti] = *reinterpret_cast<const f32x4*>(dw.b2 + 16 * (w + NW * ti) + 4 * q);
-  float b3c[MAXT];
   int fidx[MAXT];
   bool fval[MAXT];
 #pragma unroll
@@ -461,10 +519,12 @@ __global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
     const int t16 = w + NW * i;
     fidx[i] = 16 * t16 + c;
     fval[i] = t16 < dw.NT3 && fidx[i] < dw.F;
-    b3c[i] = (t16 < dw.NT3) ? dw.b3[fidx[i]] : 0.f;
   }
+  // contiguous chunk of frames per workgroup (same utterance for most consecutive frames)
+  const int per = (a.NT + gridDim.x - 1) / gridDim.x;
+  const int n_beg = blockIdx.x * per, n_end = (n_beg + per < a.NT) ? n_beg + per : a.NT;
 
-  for (int n = blockIdx.x; n < a.NT; n += gridDim.x) {
+  for (int n = n_beg; n < n_end; ++n) {
     const int utt = a.frame_utt[n];
     f32x4 bias1[TPW][2];
 #pragma unroll
@@ -485,12 +545,16 @@ __global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
         const f32x4 lo = *reinterpret_cast<const f32x4*>(src + 4 * q);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 16 + 4 * q);
         const float zz[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        split8(zz, zhi[sg], zlo[sg]);
+        split8<SPLIT>(zz, zhi[sg], zlo[sg]);
       }
-      hidden_layers<NW, 2, SPLIT>(dw, L.act1, L.act2, w, lane, zhi, zlo, bias1, bias2);
+      d.hidden(zhi, zlo, bias1);
 #pragma unroll
-      for (int i = 0; i < MAXT; ++i) { vs[i][0] = f32x4{b3c[i], b3c[i], b3c[i], b3c[i]}; vs[i][1] = vs[i][0]; }
-      out_layer_flip<NW, 2, SPLIT>(dw, L.act2, w, lane, vs);
+      for (int i = 0; i < MAXT; ++i) {
+        const float bv = (w + NW * i < dw.NT3) ? b3l[fidx[i]] : 0.f;
+        vs[i][0] = f32x4{bv, bv, bv, bv};
+        vs[i][1] = vs[i][0];
+      }
+      d.template out_layer<true>(vs);
 #pragma unroll
       for (int i = 0; i < MAXT; ++i)
 #pragma unroll
@@ -522,22 +586,30 @@ __global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
       continue;
     }
 
-    // ---- per-bin constants of frame n: X2, Vb = sum_k W[f,k] H[k,n]
+    // ---- per-bin constants of frame n: X2, rows of W, Vb = sum_k W[f,k] H[k,n]
     const float gn = a.g[n];
     float x2f[MAXT], vb[MAXT];
-    auto dotWH = [&](int i, const float (&hvec)[KP]) {   // sum_k W[utt][fidx][k] * hvec[k]
+    auto wrow = [&](int i, int k) {   // 4 consecutive ranks of W[utt][fidx[i]][:]
+      return *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + fidx[i]) * Kp + k);
+    };
+    auto dotWH = [&](int i, const float (&hvec)[KP]) {
       float v = 0.f;
-      const float* wr = a.W + ((size_t)utt * a.Fs + fidx[i]) * Kp;
 #pragma unroll
       for (int k = 0; k < Kp; k += 4) {
-        const f32x4 ww = *reinterpret_cast<const f32x4*>(wr + k);
+        const f32x4 ww = wrow(i, k);
         v += ww[0] * hvec[k] + ww[1] * hvec[k + 1] + ww[2] * hvec[k + 2] + ww[3] * hvec[k + 3];
       }
       return v;
     };
     float hs[KP];   // H[:,n] (MODE_HG: times the pending column norms of W)
 #pragma unroll
-    for (int k = 0; k < Kp; ++k) hs[k] = a.Ht[(size_t)n * Kp + k] * (MODE == MODE_HG ? a.normW[(size_t)utt * Kp + k] : 1.f);
+    for (int k = 0; k < Kp; k += 4) {
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * Kp + k);
+      f32x4 nv = {1.f, 1.f, 1.f, 1.f};
+      if (MODE == MODE_HG) nv = *reinterpret_cast<const f32x4*>(a.normW + (size_t)utt * Kp + k);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) hs[k + t] = hv[t] * nv[t];
+    }
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
       const bool tv = w + NW * i < dw.NT3;
@@ -631,18 +703,22 @@ __global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
         a1[i] = fval[i] ? s1 : 0.f;
         a2[i] = fval[i] ? s2 * x2f[i] : 0.f;
       }
+      float nuk[KP], dek[KP];
+#pragma unroll
+      for (int k = 0; k < Kp; ++k) nuk[k] = dek[k] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i)
+        if (w + NW * i < dw.NT3) {
+#pragma unroll
+          for (int k = 0; k < Kp; k += 4) {
+            const f32x4 ww = wrow(i, k);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { nuk[k + t] += ww[t] * a2[i]; dek[k + t] += ww[t] * a1[i]; }
+          }
+        }
 #pragma unroll
       for (int k = 0; k < Kp; ++k) {
-        float nu = 0.f, de = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXT; ++i)
-          if (fval[i]) {
-            const float wk = a.W[((size_t)utt * a.Fs + fidx[i]) * Kp + k];
-            nu += wk * a2[i];
-            de += wk * a1[i];
-          }
-        nu = sum_c(nu);
-        de = sum_c(de);
+        const float nu = sum_c(nuk[k]), de = sum_c(dek[k]);
         if (lane == 0) { L.redH[w][2 * k] = nu; L.redH[w][2 * k + 1] = de; }
       }
       __syncthreads();
@@ -740,25 +816,57 @@ DecW make_decw(const vaenmf_plan* p) {
   return d;
 }
 
+constexpr int LDS_LIMIT = 160 * 1024;
+
+// LDS bytes and W3 placement: W3 fragments go to LDS when they fit, else stream from L2
+template <bool SPLIT>
+void lds_plan(int NT3, size_t extra, int* w3_off, size_t* total) {
+  const size_t base = (LdsMap<SPLIT>::common_end + extra + 15) / 16 * 16;
+  const size_t w3 = LdsMap<SPLIT>::w3_bytes(NT3);
+  if (base + w3 <= (size_t)LDS_LIMIT) { *w3_off = (int)base; *total = base + w3; }
+  else { *w3_off = -1; *total = base; }
+}
+
 template <int NW, bool SPLIT>
-int launch_chain(const ChainArgs& a, int n_tiles, hipStream_t st) {
-  hipLaunchKernelGGL((mh_chain_kernel<NW, SPLIT>), dim3(n_tiles), dim3(NW * 64), sizeof(ChainLds), st, a);
+int launch_chain(ChainArgs a, int n_tiles, hipStream_t st) {
+  size_t lds;
+  lds_plan<SPLIT>(a.dw.NT3, sizeof(ChainX), &a.w3_lds_off, &lds);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, SPLIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, SPLIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+    attr_done = true;
+  }
+  if (a.w3_lds_off >= 0) hipLaunchKernelGGL((mh_chain_kernel<NW, SPLIT, true>), dim3(n_tiles), dim3(NW * 64), lds, st, a);
+  else                   hipLaunchKernelGGL((mh_chain_kernel<NW, SPLIT, false>), dim3(n_tiles), dim3(NW * 64), lds, st, a);
   return 0;
 }
 
+template <int NW, bool SPLIT, int MODE, int KP>
+void launch_decode_one(const DecodeArgs& a, int grid, size_t lds, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)decode_kernel<NW, SPLIT, true, MODE, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+    (void)hipFuncSetAttribute((const void*)decode_kernel<NW, SPLIT, false, MODE, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+    attr_done = true;
+  }
+  if (a.w3_lds_off >= 0) hipLaunchKernelGGL((decode_kernel<NW, SPLIT, true, MODE, KP>), dim3(grid), dim3(NW * 64), lds, st, a);
+  else                   hipLaunchKernelGGL((decode_kernel<NW, SPLIT, false, MODE, KP>), dim3(grid), dim3(NW * 64), lds, st, a);
+}
 template <int NW, bool SPLIT, int MODE>
-int launch_decode_kp(const DecodeArgs& a, int Kp, int grid, hipStream_t st) {
-  const size_t lds = sizeof(DecodeLds);
+int launch_decode_kp(DecodeArgs a, int Kp, int grid, hipStream_t st) {
+  size_t lds;
+  lds_plan<SPLIT>(a.dw.NT3, sizeof(DecodeX), &a.w3_lds_off, &lds);
   switch (Kp) {
-    case 8:  hipLaunchKernelGGL((decode_kernel<NW, SPLIT, MODE, 8>), dim3(grid), dim3(NW * 64), lds, st, a); break;
-    case 16: hipLaunchKernelGGL((decode_kernel<NW, SPLIT, MODE, 16>), dim3(grid), dim3(NW * 64), lds, st, a); break;
-    default: hipLaunchKernelGGL((decode_kernel<NW, SPLIT, MODE, 32>), dim3(grid), dim3(NW * 64), lds, st, a); break;
+    case 8:  launch_decode_one<NW, SPLIT, MODE, 8>(a, grid, lds, st); break;
+    case 16: launch_decode_one<NW, SPLIT, MODE, 16>(a, grid, lds, st); break;
+    default: launch_decode_one<NW, SPLIT, MODE, 32>(a, grid, lds, st); break;
   }
   return 0;
 }
 template <int MODE>
 int launch_decode(const vaenmf_plan* p, const DecodeArgs& a, hipStream_t st) {
-  const int grid = a.NT < p->n_sms * 8 ? a.NT : p->n_sms * 8;
+  const int grid = a.NT < p->n_sms * 4 ? a.NT : p->n_sms * 4;
   const bool split = p->cfg.precision == VAENMF_PREC_BF16X3;
   const int Kp = (MODE == MODE_STORE) ? 8 : p->Kp;
   if (p->nwaves == 4) return split ? launch_decode_kp<4, true, MODE>(a, Kp, grid, st) : launch_decode_kp<4, false, MODE>(a, Kp, grid, st);
