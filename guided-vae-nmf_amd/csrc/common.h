@@ -28,7 +28,7 @@ void vaenmf_set_error(const char* fmt, ...);
     }                                        \
   } while (0)
 
-constexpr int FRAMES_PER_TILE = 32;   // MH chain: frames per workgroup (2 MFMA column groups of 16)
+constexpr int MAX_TILE_FRAMES = 64;   // MH chain: frames per workgroup = 32 per team (2 MFMA column groups of 16)
 constexpr int MAXT = 5;               // feature tiles (16 bins each) per wave in the last layer
 constexpr int LAT = 32;               // latent dimension handled by the MFMA path
 constexpr int HID = 128;              // hidden width of both decoder layers
@@ -36,7 +36,8 @@ constexpr int HID = 128;              // hidden width of both decoder layers
 struct vaenmf_plan {
   vaenmf_config cfg;
   int Fs, Kp, NT3;           // padded bins, padded rank, feature tiles of 16 in the last layer
-  int nwaves;                // waves per workgroup that split the features (4: F<=320, 8: F<=640)
+  int nwaves;                // waves of a team that split the features (4: F<=320, 8: F<=640)
+  int tile_frames;           // MH-chain frames per workgroup: 64 (2 teams of 4 waves) or 32 (1 team of 8)
   // decoder weights on the device, MFMA fragment order (see weights in plan.hip)
   __bf16 *w1f, *w2f, *w3f;   // [tile][kstep][part hi/lo][lane][8]
   float *b1, *b2, *b3;       // biases (b3 padded to 16*NT3)

@@ -21,6 +21,7 @@ namespace {
 
 constexpr int NK_H = HID / 32;     // k-steps over a hidden layer (4)
 constexpr int NT_H = HID / 16;     // feature tiles of a hidden layer (8)
+constexpr int TEAM_COLS = 32;      // MLP input rows ("columns") per team and pass: 2 MFMA column groups
 
 struct DecW {                      // decoder weights (device), fragment order [tile][kstep][part][lane][8]
   const __bf16 *w1f, *w2f, *w3f;
@@ -29,26 +30,32 @@ struct DecW {                      // decoder weights (device), fragment order [
   int F;
 };
 
-// ---- LDS carve (one dynamic array; every offset a multiple of 16) ------------------
-// act1/act2: activation images [col group][k-step][part][lane][8 bf16]   (2 col groups)
-// w1/w2(/w3): weight fragments, PARTS = 2 (hi,lo) in bf16x3 mode, 1 in bf16 mode
-template <bool SPLIT>
+// A workgroup = NTEAM teams x NW waves.  The NW waves of a team split the output features of
+// every layer and share 32 columns (MH chain: 32 frames; decode: 32 samples of one frame);
+// the teams work on different columns, share the LDS-resident weights and run in lockstep
+// (workgroup barriers), so the two waves a SIMD hosts overlap each other's LDS / L2 latency
+// and VALU issue.
+//
+// LDS carve (one dynamic array; every offset a multiple of 16):
+//   w1, w2 (, w3)  weight fragments, PARTS = 2 (hi,lo) in bf16x3 mode, 1 in bf16 mode
+//   act[team]      activation image [col group][k-step][part][lane][8 bf16]; layer 1 and
+//                  layer 2 images alias each other in bf16x3 mode (one more barrier)
+template <int NTEAM, bool SPLIT>
 struct LdsMap {
   static constexpr int PARTS = SPLIT ? 2 : 1;
-  static constexpr int ACT = 2 * NK_H * 2 * 1024;
+  static constexpr bool ALIAS = SPLIT;                      // act2 aliases act1
+  static constexpr int ACT = 2 * NK_H * PARTS * 1024;       // one image (2 col groups)
+  static constexpr int ACT_TEAM = ALIAS ? ACT : 2 * ACT;
   static constexpr int W1B = NT_H * 1 * PARTS * 1024;
   static constexpr int W2B = NT_H * NK_H * PARTS * 1024;
-  static constexpr int act1 = 0;
-  static constexpr int act2 = act1 + ACT;
-  static constexpr int w1 = act2 + ACT;
+  static constexpr int act = 0;
+  static constexpr int w1 = act + NTEAM * ACT_TEAM;
   static constexpr int w2 = w1 + W1B;
   static constexpr int b2 = w2 + W2B;              // float[HID]
-  static constexpr int b3 = b2 + HID * 4;          // float[Fs_max = 640]
+  static constexpr int b3 = b2 + HID * 4;          // float[640]
   static constexpr int common_end = b3 + 640 * 4;
   static __host__ __device__ constexpr int w3_bytes(int NT3) { return NT3 * NK_H * PARTS * 1024; }
 };
-
-__device__ __forceinline__ int act_off(int cg, int s, int part) { return ((cg * NK_H + s) * 2 + part) * 1024; }
 
 // copy fragment blocks global -> LDS (PARTS==1 keeps the hi block only)
 template <int PARTS>
@@ -91,34 +98,20 @@ __device__ __forceinline__ void split8(const float (&z)[8], bf16x8& hi, bf16x8& 
   }
 }
 
-// tanh + split + store one accumulator tile (feature tile `tile`) into the LDS image
-template <bool SPLIT>
-__device__ __forceinline__ void store_act(char* act, int lane16, int cg, int tile, f32x4 acc) {
-  f32x4 h;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) h[t] = fast_tanh(acc[t]);
-  const int s = tile >> 1, e = tile & 1;
-  bf16x4 hi, lo;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    __bf16 x = (__bf16)h[t];
-    hi[t] = x;
-    lo[t] = (__bf16)(h[t] - (float)x);
-  }
-  *reinterpret_cast<bf16x4*>(act + act_off(cg, s, 0) + lane16 + e * 8) = hi;
-  if (SPLIT) *reinterpret_cast<bf16x4*>(act + act_off(cg, s, 1) + lane16 + e * 8) = lo;
-}
-
-// Everything a wave needs to run the decoder: LDS pointers + its (uniform) wave index.
-template <int NW, bool SPLIT, bool W3LDS>
+// Everything a wave needs to run the decoder: LDS pointers + its (uniform) team / wave index.
+template <int NW, int NTEAM, bool SPLIT, bool W3LDS>
 struct Dec {
-  using M = LdsMap<SPLIT>;
+  using M = LdsMap<NTEAM, SPLIT>;
   static constexpr int TPW = NT_H / NW;
   char* lds;
+  char* act1;           // this team's layer-1 image
+  char* act2;           // this team's layer-2 image (== act1 when aliased)
   const char* w3g;      // global W3 fragments of this wave's first tile (uniform pointer)   [!W3LDS]
   const char* w3l;      // LDS W3 fragments                                                  [W3LDS]
-  int w, NT3;
+  int w, team, NT3;
   unsigned lane16;
+
+  static __device__ __forceinline__ int act_off(int cg, int s) { return (cg * NK_H + s) * M::PARTS * 1024; }
 
   __device__ __forceinline__ void lds_w(int base, int tile, int nk, int s, bf16x8& hi, bf16x8& lo) const {
     const char* p = lds + base + ((tile * nk + s) * M::PARTS) * 1024 + lane16;
@@ -136,25 +129,43 @@ struct Dec {
       if (SPLIT) lo = *reinterpret_cast<const bf16x8*>(p + 1024); else lo = hi;
     }
   }
-  __device__ __forceinline__ void act_frag(int which, int cg, int s, bf16x8& hi, bf16x8& lo) const {
-    const char* p = lds + (which ? M::act2 : M::act1) + act_off(cg, s, 0) + lane16;
+  __device__ __forceinline__ void act_frag(const char* img, int cg, int s, bf16x8& hi, bf16x8& lo) const {
+    const char* p = img + act_off(cg, s) + lane16;
     hi = *reinterpret_cast<const bf16x8*>(p);
     if (SPLIT) lo = *reinterpret_cast<const bf16x8*>(p + 1024); else lo = hi;
   }
+  // tanh + split + store one accumulator tile (feature tile `tile`) into an LDS image
+  __device__ __forceinline__ void store_act(char* img, int cg, int tile, f32x4 acc) const {
+    f32x4 h;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h[t] = fast_tanh(acc[t]);
+    const int s = tile >> 1, e = tile & 1;
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      __bf16 x = (__bf16)h[t];
+      hi[t] = x;
+      lo[t] = (__bf16)(h[t] - (float)x);
+    }
+    *reinterpret_cast<bf16x4*>(img + act_off(cg, s) + lane16 + e * 8) = hi;
+    if (SPLIT) *reinterpret_cast<bf16x4*>(img + act_off(cg, s) + 1024 + lane16 + e * 8) = lo;
+  }
 
-  // Hidden layers 1 and 2 for two column groups.  zhi/zlo: layer-1 B fragments (latent rows);
-  // bias1[ti][cg]: accumulator init of layer 1.  Leaves tanh(layer 2) in act2.  Two barriers.
-  __device__ __forceinline__ void hidden(const bf16x8 (&zhi)[2], const bf16x8 (&zlo)[2], const f32x4 (&bias1)[TPW][2]) const {
+  // Hidden layers 1 and 2 for this team's two column groups.  zhi/zlo: layer-1 B fragments
+  // (latent rows); bias1[ti][cg]: accumulator init of layer 1.  Leaves tanh(layer 2) in act2.
+  // `between` runs after the first barrier (all waves have consumed the previous step's noise).
+  template <typename F>
+  __device__ __forceinline__ void hidden(const bf16x8 (&zhi)[2], const bf16x8 (&zlo)[2], const f32x4 (&bias1)[TPW][2], F between) const {
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
       const int tile = w + NW * ti;
       bf16x8 whi, wlo;
       lds_w(M::w1, tile, 1, 0, whi, wlo);
 #pragma unroll
-      for (int cg = 0; cg < 2; ++cg)
-        store_act<SPLIT>(lds + M::act1, lane16, cg, tile, mma3<SPLIT>(whi, wlo, zhi[cg], zlo[cg], bias1[ti][cg]));
+      for (int cg = 0; cg < 2; ++cg) store_act(act1, cg, tile, mma3<SPLIT>(whi, wlo, zhi[cg], zlo[cg], bias1[ti][cg]));
     }
     __syncthreads();
+    between();
     f32x4 acc2[TPW][2];
     const float* b2 = reinterpret_cast<const float*>(lds + M::b2);
 #pragma unroll
@@ -165,8 +176,8 @@ struct Dec {
 #pragma unroll
     for (int s = 0; s < NK_H; ++s) {
       bf16x8 ahi[2], alo[2];
-      act_frag(0, 0, s, ahi[0], alo[0]);
-      act_frag(0, 1, s, ahi[1], alo[1]);
+      act_frag(act1, 0, s, ahi[0], alo[0]);
+      act_frag(act1, 1, s, ahi[1], alo[1]);
 #pragma unroll
       for (int ti = 0; ti < TPW; ++ti) {
         bf16x8 whi, wlo;
@@ -175,10 +186,11 @@ struct Dec {
         for (int cg = 0; cg < 2; ++cg) acc2[ti][cg] = mma3<SPLIT>(whi, wlo, ahi[cg], alo[cg], acc2[ti][cg]);
       }
     }
+    if (M::ALIAS) __syncthreads();      // every wave is done reading the layer-1 image
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti)
 #pragma unroll
-      for (int cg = 0; cg < 2; ++cg) store_act<SPLIT>(lds + M::act2, lane16, cg, w + NW * ti, acc2[ti][cg]);
+      for (int cg = 0; cg < 2; ++cg) store_act(act2, cg, w + NW * ti, acc2[ti][cg]);
     __syncthreads();
   }
 
@@ -189,8 +201,8 @@ struct Dec {
 #pragma unroll
     for (int s = 0; s < NK_H; ++s) {
       bf16x8 ahi[2], alo[2];
-      act_frag(1, 0, s, ahi[0], alo[0]);
-      act_frag(1, 1, s, ahi[1], alo[1]);
+      act_frag(act2, 0, s, ahi[0], alo[0]);
+      act_frag(act2, 1, s, ahi[1], alo[1]);
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
         if (w + NW * i < NT3) {   // wave-uniform (w is an SGPR value)
@@ -207,14 +219,18 @@ struct Dec {
 };
 
 // workgroup prologue shared by both kernels: stage W1/W2 (and W3 when it fits), b2, b3 into LDS
-template <int NW, bool SPLIT, bool W3LDS>
-__device__ __forceinline__ Dec<NW, SPLIT, W3LDS> dec_setup(char* smem, const DecW& dw, int w3_lds_off, int Fs) {
-  using M = LdsMap<SPLIT>;
-  Dec<NW, SPLIT, W3LDS> d;
+template <int NW, int NTEAM, bool SPLIT, bool W3LDS>
+__device__ __forceinline__ Dec<NW, NTEAM, SPLIT, W3LDS> dec_setup(char* smem, const DecW& dw, int w3_lds_off, int Fs) {
+  using M = LdsMap<NTEAM, SPLIT>;
+  Dec<NW, NTEAM, SPLIT, W3LDS> d;
   d.lds = smem;
-  d.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  d.team = wid / NW;
+  d.w = wid - d.team * NW;
   d.lane16 = (threadIdx.x & 63) * 16;
   d.NT3 = dw.NT3;
+  d.act1 = smem + M::act + d.team * M::ACT_TEAM;
+  d.act2 = M::ALIAS ? d.act1 : d.act1 + M::ACT;
   d.w3g = reinterpret_cast<const char*>(dw.w3f) + (size_t)d.w * NK_H * 2 * 1024;
   d.w3l = smem + (W3LDS ? w3_lds_off : 0);
   stage_weights<M::PARTS>(smem + M::w1, dw.w1f, NT_H);
@@ -245,33 +261,30 @@ struct ChainArgs {
   float sd;                  // sqrt(var_RW)
 };
 
-// chain-specific LDS after LdsMap::common_end
+// chain-specific LDS after LdsMap::common_end, one per team
 struct ChainX {
-  float b1tab[FRAMES_PER_TILE][HID];      // layer-1 accumulator init per frame (b1 or B1[n])
-  float eps[2][FRAMES_PER_TILE][LAT];
-  float u[2][FRAMES_PER_TILE];
-  double epart[2][8][FRAMES_PER_TILE];
+  float eps[TEAM_COLS][LAT];
+  float u[TEAM_COLS];
+  double epart[2][8][TEAM_COLS];
 };
 
-template <int NW, bool SPLIT, bool W3LDS>
-__global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
+template <int NW, int NTEAM, bool SPLIT, bool W3LDS>
+__global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using M = LdsMap<SPLIT>;
+  using M = LdsMap<NTEAM, SPLIT>;
   constexpr int TPW = NT_H / NW;
-  ChainX& L = *reinterpret_cast<ChainX*>(smem + M::common_end);
   const DecW& dw = a.dw;
-  const Dec<NW, SPLIT, W3LDS> d = dec_setup<NW, SPLIT, W3LDS>(smem, dw, a.w3_lds_off, a.Fs);
+  const Dec<NW, NTEAM, SPLIT, W3LDS> d = dec_setup<NW, NTEAM, SPLIT, W3LDS>(smem, dw, a.w3_lds_off, a.Fs);
+  ChainX& L = reinterpret_cast<ChainX*>(smem + M::common_end)[d.team];
   const int lane = threadIdx.x & 63, w = d.w, q = lane >> 4, c = lane & 15;
   const int tile = blockIdx.x;
-  const int utt = a.tile_utt[tile], n0 = a.tile_n0[tile], cnt = a.tile_cnt[tile];
-
-  // layer-1 bias table (per frame for M2: b1 + W1y y_n, folded by vaenmf_layer1_bias)
-  for (int e = threadIdx.x; e < FRAMES_PER_TILE * HID / 4; e += blockDim.x) {
-    const int fr = e / (HID / 4), h4 = e - fr * (HID / 4);
-    const int nr = n0 + (fr < cnt ? fr : cnt - 1);
-    reinterpret_cast<f32x4*>(&L.b1tab[fr][0])[h4] =
-        a.B1 ? reinterpret_cast<const f32x4*>(a.B1 + (size_t)nr * HID)[h4] : reinterpret_cast<const f32x4*>(dw.b1)[h4];
-  }
+  const int utt = a.tile_utt[tile];
+  const int cnt_all = a.tile_cnt[tile];                                 // <= 32*NTEAM frames, one utterance
+  int cnt = cnt_all - TEAM_COLS * d.team;                               // this team's share
+  cnt = cnt < 0 ? 0 : (cnt > TEAM_COLS ? TEAM_COLS : cnt);
+  const bool team_on = cnt > 0;
+  const int n0 = a.tile_n0[tile] + (team_on ? TEAM_COLS * d.team : 0);  // idle team shadows team 0 (no stores)
+  if (!team_on) cnt = cnt_all < TEAM_COLS ? cnt_all : TEAM_COLS;
 
   // ---- frames of this lane (one per column group)
   int nrow[2];
@@ -280,11 +293,12 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
 #pragma unroll
   for (int fg = 0; fg < 2; ++fg) {
     const int j = 16 * fg + c;
-    fvalid[fg] = j < cnt;
+    fvalid[fg] = team_on && j < cnt;
     nrow[fg] = n0 + (j < cnt ? j : cnt - 1);
     gn[fg] = a.g[nrow[fg]];
   }
-  // ---- per-(bin,frame) constants in accumulator layout: X2 and Vb = W H (mcem.py:81-82)
+  // ---- per-(bin,frame) constants in accumulator layout: X2 and Vb = W H (mcem.py:81-82).
+  // Padding bins get X2 = 0, Vb = 1 and (through b3 = -100, W3 = 0) Vs = 0: their term is exactly 0.
   f32x4 x2[MAXT][2], vb[MAXT][2];
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
@@ -293,7 +307,7 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
     const bool tv = t16 < dw.NT3;
 #pragma unroll
     for (int fg = 0; fg < 2; ++fg) {
-      x2[i][fg] = tv ? *reinterpret_cast<const f32x4*>(a.X2 + (size_t)nrow[fg] * a.Fs + f0) : f32x4{0, 0, 0, 0};
+      f32x4 xv = tv ? *reinterpret_cast<const f32x4*>(a.X2 + (size_t)nrow[fg] * a.Fs + f0) : f32x4{0, 0, 0, 0};
       f32x4 v = {0, 0, 0, 0};
       if (tv) {
         for (int k = 0; k < a.Kp; k += 4) {
@@ -305,8 +319,22 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
           }
         }
       }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (f0 + t >= dw.F) { xv[t] = 0.f; v[t] = 1.f; }
+      x2[i][fg] = xv;
       vb[i][fg] = v;
     }
+  }
+  // ---- layer-1 accumulator init: b1, or per frame b1 + W1y y_n (M2, folded by vaenmf_layer1_bias)
+  f32x4 bias1[TPW][2];
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti) {
+    const int f0 = 16 * (w + NW * ti) + 4 * q;
+#pragma unroll
+    for (int fg = 0; fg < 2; ++fg)
+      bias1[ti][fg] = a.B1 ? *reinterpret_cast<const f32x4*>(a.B1 + (size_t)nrow[fg] * HID + f0)
+                           : *reinterpret_cast<const f32x4*>(dw.b1 + f0);
   }
   // ---- current latent state, fragment order: latents 4q..4q+3 and 16+4q..16+4q+3
   float z[2][8];
@@ -317,14 +345,14 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) { z[fg][t] = lo[t]; z[fg][4 + t] = hi[t]; }
   }
-  // ---- noise streams: thread id <-> (frame of the tile, latent quad); 256 streams
-  const int sid = threadIdx.x, sfr = sid >> 3, squad = sid & 7;
-  const bool srng = sid < FRAMES_PER_TILE * 8;
-  const bool sval = srng && sfr < cnt;
+  // ---- noise streams: thread of the team <-> (frame of the team, latent quad); 256 streams
+  const int sid = threadIdx.x - d.team * NW * 64, sfr = sid >> 3, squad = sid & 7;
+  const bool srng = sid < TEAM_COLS * 8;
+  const bool sval = srng && team_on && sfr < cnt;
   Xs128 st;
   if (sval && a.rng_mode == VAENMF_RNG_DEVICE)
     st = xs_seed(a.utt_seed[utt], (uint32_t)(n0 - a.frame_off[utt] + sfr), (uint32_t)squad, a.call);
-  auto draw = [&](int step) {   // noise of MH step `step` -> LDS buffer step&1
+  auto draw = [&](int step) {   // noise of MH step `step` -> LDS (single buffer, see Dec::hidden)
     if (!srng) return;
     f32x4 e = {0, 0, 0, 0};
     float uu = 0.5f;
@@ -338,26 +366,21 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
         if (squad == 0) uu = a.u[row];
       }
     }
-    *reinterpret_cast<f32x4*>(&L.eps[step & 1][sfr][4 * squad]) = e;
-    if (squad == 0) L.u[step & 1][sfr] = uu;
+    *reinterpret_cast<f32x4*>(&L.eps[sfr][4 * squad]) = e;
+    if (squad == 0) L.u[sfr] = uu;
   };
 
   int ecount = 0;
   const float* b3l = reinterpret_cast<const float*>(smem + M::b3);
+  const int S = a.nsamples + a.burnin;
   // E(z) = sum_f [log Vx + X2/Vx] per frame (fp64 accumulation: the reference sums the
   // per-bin DIFFERENCES of two states, mcem.py:415-416; summing each state separately
   // needs the extra bits to keep the same absolute accuracy).
-  auto energy = [&](const float (&zz)[2][8], double (&E)[2]) {
+  auto energy = [&](const float (&zz)[2][8], double (&E)[2], int next_step) {
     bf16x8 zhi[2], zlo[2];
     split8<SPLIT>(zz[0], zhi[0], zlo[0]);
     split8<SPLIT>(zz[1], zhi[1], zlo[1]);
-    f32x4 bias1[TPW][2];
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti)
-#pragma unroll
-      for (int fg = 0; fg < 2; ++fg)
-        bias1[ti][fg] = *reinterpret_cast<const f32x4*>(&L.b1tab[16 * fg + c][16 * (w + NW * ti) + 4 * q]);
-    d.hidden(zhi, zlo, bias1);
+    d.hidden(zhi, zlo, bias1, [&]() { if (next_step < S) draw(next_step); });
     f32x4 acc[MAXT][2];
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
@@ -368,8 +391,7 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
     double e[2] = {0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
-      const int t16 = w + NW * i;
-      if (t16 < dw.NT3) {
+      if (w + NW * i < dw.NT3) {
 #pragma unroll
         for (int fg = 0; fg < 2; ++fg) {
           float part = 0.f;
@@ -377,8 +399,7 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
           for (int t = 0; t < 4; ++t) {
             const float vs = fast_exp(acc[i][fg][t]);
             const float vx = gn[fg] * vs + vb[i][fg][t];
-            const float term = fast_log(vx) + x2[i][fg][t] * fast_rcp(vx);
-            part += (16 * t16 + 4 * q + t < dw.F) ? term : 0.f;
+            part += fast_log(vx) + x2[i][fg][t] * fast_rcp(vx);
           }
           e[fg] += (double)part;
         }
@@ -402,43 +423,48 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
     }
   };
 
-  const int S = a.nsamples + a.burnin;
-  draw(0);
-  __syncthreads();                                    // staged weights, bias tables, first noise
+  __syncthreads();                                    // staged weights and biases
   double Ecur[2] = {0.0, 0.0};
   // m = -1 evaluates the initial state, Vs_t = decoder(Z_t) (mcem.py:392-400); m >= 0 are the MH steps
   for (int m = -1; m < S; ++m) {
     // ---- proposal  Z' = Z + sqrt(var) * randn   (mcem.py:407)
     float zp[2][8];
+    float e8[2][8];
     const float sd = m < 0 ? 0.f : a.sd;
-    const int eb = m & 1;
 #pragma unroll
     for (int fg = 0; fg < 2; ++fg) {
-      const f32x4 e0 = *reinterpret_cast<const f32x4*>(&L.eps[eb][16 * fg + c][4 * q]);
-      const f32x4 e1 = *reinterpret_cast<const f32x4*>(&L.eps[eb][16 * fg + c][16 + 4 * q]);
+      f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
+      if (m >= 0) {
+        e0 = *reinterpret_cast<const f32x4*>(&L.eps[16 * fg + c][4 * q]);
+        e1 = *reinterpret_cast<const f32x4*>(&L.eps[16 * fg + c][16 + 4 * q]);
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
+        e8[fg][t] = e0[t]; e8[fg][4 + t] = e1[t];
         zp[fg][t] = z[fg][t] + sd * e0[t];
         zp[fg][4 + t] = z[fg][4 + t] + sd * e1[t];
       }
     }
-    if (m >= 0 && m + 1 < S) draw(m + 1);
+    const float uu0 = m >= 0 ? L.u[c] : 1.f, uu1 = m >= 0 ? L.u[16 + c] : 1.f;
     double Ep[2];
-    energy(zp, Ep);                                   // mcem.py:410-412
+    energy(zp, Ep, m + 1);                            // mcem.py:410-412 (draws the next step's noise inside)
 #pragma unroll
     for (int fg = 0; fg < 2; ++fg) {
       float pr = 0.f;                                 // .5*sum(Z^2 - Z'^2)  (mcem.py:417)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pr += z[fg][j] * z[fg][j] - zp[fg][j] * zp[fg][j];
+      for (int j = 0; j < 8; ++j) {
+        const float zn = z[fg][j] + sd * e8[fg][j];
+        pr += z[fg][j] * z[fg][j] - zn * zn;
+      }
       pr += __shfl_xor(pr, 16, 64);
       pr += __shfl_xor(pr, 32, 64);
       const float accp = (float)(Ecur[fg] - Ep[fg]) + 0.5f * pr;
-      const float uu = L.u[eb][16 * fg + c];
+      const float uu = fg == 0 ? uu0 : uu1;
       const bool ok = m < 0 || fast_log(uu) < accp;   // mcem.py:420
       if (a.acc_out && m >= 0 && w == 0 && q == 0 && fvalid[fg]) a.acc_out[(size_t)m * a.NT + nrow[fg]] = accp;
       if (ok) {                                       // mcem.py:429-433
 #pragma unroll
-        for (int j = 0; j < 8; ++j) z[fg][j] = zp[fg][j];
+        for (int j = 0; j < 8; ++j) z[fg][j] = z[fg][j] + sd * e8[fg][j];
         Ecur[fg] = Ep[fg];
       }
       if (m >= a.burnin && w == 0 && fvalid[fg]) {    // mcem.py:435-437
@@ -459,7 +485,7 @@ __global__ __launch_bounds__(NW * 64) void mh_chain_kernel(const ChainArgs a) {
   }
 }
 
-// same streams as mh_chain_kernel::draw, written to global memory (test aid)
+// same streams as mh_chain_kernel::draw, written to global memory (test aid); blockDim = 8 * tile frames
 __global__ void rng_fill_kernel(const int32_t* tile_utt, const int32_t* tile_n0, const int32_t* tile_cnt,
                                 const int32_t* frame_off, const uint64_t* utt_seed, uint32_t call, int S, int NT,
                                 float* eps_out, float* u_out) {
@@ -492,21 +518,21 @@ struct DecodeArgs {
   int w3_lds_off;
 };
 
-struct DecodeX {
+struct DecodeX {            // one per team
   float redH[8][64];        // [wave][2*Kp]
   float redG[8][2];
   double redC[8];
 };
 
-template <int NW, bool SPLIT, bool W3LDS, int MODE, int KP>
-__global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
+template <int NW, int NTEAM, bool SPLIT, bool W3LDS, int MODE, int KP>
+__global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using M = LdsMap<SPLIT>;
+  using M = LdsMap<NTEAM, SPLIT>;
   constexpr int TPW = NT_H / NW;
   constexpr int Kp = KP;
-  DecodeX& L = *reinterpret_cast<DecodeX*>(smem + M::common_end);
   const DecW& dw = a.dw;
-  const Dec<NW, SPLIT, W3LDS> d = dec_setup<NW, SPLIT, W3LDS>(smem, dw, a.w3_lds_off, a.Fs);
+  const Dec<NW, NTEAM, SPLIT, W3LDS> d = dec_setup<NW, NTEAM, SPLIT, W3LDS>(smem, dw, a.w3_lds_off, a.Fs);
+  DecodeX& L = reinterpret_cast<DecodeX*>(smem + M::common_end)[d.team];
   const int lane = threadIdx.x & 63, w = d.w, q = lane >> 4, c = lane & 15;
   const int nch = (a.R + 31) / 32;
   const float* b3l = reinterpret_cast<const float*>(smem + M::b3);
@@ -520,11 +546,13 @@ __global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
     fidx[i] = 16 * t16 + c;
     fval[i] = t16 < dw.NT3 && fidx[i] < dw.F;
   }
-  // contiguous chunk of frames per workgroup (same utterance for most consecutive frames)
+  // contiguous chunk of frames per workgroup; the teams take alternate frames of the chunk
   const int per = (a.NT + gridDim.x - 1) / gridDim.x;
   const int n_beg = blockIdx.x * per, n_end = (n_beg + per < a.NT) ? n_beg + per : a.NT;
 
-  for (int n = n_beg; n < n_end; ++n) {
+  for (int nb = n_beg; nb < n_end; nb += NTEAM) {
+    const bool on = nb + d.team < n_end;          // team without a frame shadows the last one, stores masked
+    const int n = on ? nb + d.team : n_end - 1;
     const int utt = a.frame_utt[n];
     f32x4 bias1[TPW][2];
 #pragma unroll
@@ -547,7 +575,7 @@ __global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
         const float zz[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         split8<SPLIT>(zz, zhi[sg], zlo[sg]);
       }
-      d.hidden(zhi, zlo, bias1);
+      d.hidden(zhi, zlo, bias1, []() {});
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
         const float bv = (w + NW * i < dw.NT3) ? b3l[fidx[i]] : 0.f;
@@ -573,15 +601,17 @@ __global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
       for (int ch = 0; ch < nch; ++ch) {
         f32x4 vs[MAXT][2];
         decode_chunk(ch, vs);
+        if (on) {
 #pragma unroll
-        for (int i = 0; i < MAXT; ++i)
-          if (w + NW * i < dw.NT3)
+          for (int i = 0; i < MAXT; ++i)
+            if (w + NW * i < dw.NT3)
 #pragma unroll
-            for (int sg = 0; sg < 2; ++sg)
+              for (int sg = 0; sg < 2; ++sg)
 #pragma unroll
-              for (int t = 0; t < 4; ++t)
-                if (rvalid(ch, sg, t))
-                  a.Vs_out[((size_t)n * a.R + 32 * ch + 16 * sg + 4 * q + t) * a.Fs + fidx[i]] = fval[i] ? vs[i][sg][t] : 0.f;
+                for (int t = 0; t < 4; ++t)
+                  if (rvalid(ch, sg, t))
+                    a.Vs_out[((size_t)n * a.R + 32 * ch + 16 * sg + 4 * q + t) * a.Fs + fidx[i]] = fval[i] ? vs[i][sg][t] : 0.f;
+        }
       }
       continue;
     }
@@ -639,7 +669,7 @@ __global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
         const float s1 = sum_q(a1[i]), s2 = sum_q(a2[i]);
-        if (q == 0 && w + NW * i < dw.NT3) {
+        if (on && q == 0 && w + NW * i < dw.NT3) {
           a.A1[(size_t)n * a.Fs + fidx[i]] = fval[i] ? s1 : 0.f;
           a.P[(size_t)n * a.Fs + fidx[i]] = fval[i] ? x2f[i] * s2 : 0.f;
         }
@@ -669,7 +699,7 @@ __global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
         const float s = sum_q(ws[i]) * invR, nn = sum_q(wn[i]) * invR;
-        if (q == 0 && w + NW * i < dw.NT3) {
+        if (on && q == 0 && w + NW * i < dw.NT3) {
           const size_t o = (size_t)n * a.Fs + fidx[i];
           const float xr = a.X[2 * o], xi = a.X[2 * o + 1];
           a.S_hat[2 * o] = fval[i] ? s * xr : 0.f;  a.S_hat[2 * o + 1] = fval[i] ? s * xi : 0.f;   // mcem.py:175
@@ -730,7 +760,7 @@ __global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
         for (int ww = 0; ww < NW; ++ww) { nu += L.redH[ww][2 * k]; de += L.redH[ww][2 * k + 1]; }
         hn[k] = (k < a.K) ? hs[k] * sqrtf(nu / de) : 0.f;
       }
-      if (threadIdx.x == 0) {
+      if (on && w == 0 && lane == 0) {
 #pragma unroll
         for (int k = 0; k < Kp; k += 4)
           *reinterpret_cast<f32x4*>(a.Ht + (size_t)n * Kp + k) = f32x4{hn[k], hn[k + 1], hn[k + 2], hn[k + 3]};
@@ -770,7 +800,7 @@ __global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
 #pragma unroll
       for (int ww = 0; ww < NW; ++ww) { nu += L.redG[ww][0]; de += L.redG[ww][1]; }
       const float gnew = gn * sqrtf(nu / de);
-      if (threadIdx.x == 0) a.g[n] = gnew;
+      if (on && w == 0 && lane == 0) a.g[n] = gnew;
       // ---- cost (mcem.py:70) with the refreshed variances (mcem.py:151-152)
       float cs = 0.f;
       for (int ch = 0; ch < nch; ++ch) {
@@ -792,7 +822,7 @@ __global__ __launch_bounds__(NW * 64) void decode_kernel(const DecodeArgs a) {
       cd += shfl_xor_d(cd, 16); cd += shfl_xor_d(cd, 32);
       if (lane == 0) L.redC[w] = cd;
       __syncthreads();
-      if (threadIdx.x == 0) {
+      if (on && w == 0 && lane == 0) {
         double s = 0.0;
         for (int ww = 0; ww < NW; ++ww) s += L.redC[ww];
         a.cost_frames[n] = s;
@@ -819,58 +849,62 @@ DecW make_decw(const vaenmf_plan* p) {
 constexpr int LDS_LIMIT = 160 * 1024;
 
 // LDS bytes and W3 placement: W3 fragments go to LDS when they fit, else stream from L2
-template <bool SPLIT>
-void lds_plan(int NT3, size_t extra, int* w3_off, size_t* total) {
-  const size_t base = (LdsMap<SPLIT>::common_end + extra + 15) / 16 * 16;
-  const size_t w3 = LdsMap<SPLIT>::w3_bytes(NT3);
+template <int NTEAM, bool SPLIT>
+void lds_plan(int NT3, size_t extra_per_team, int* w3_off, size_t* total) {
+  using M = LdsMap<NTEAM, SPLIT>;
+  const size_t base = (M::common_end + NTEAM * extra_per_team + 15) / 16 * 16;
+  const size_t w3 = M::w3_bytes(NT3);
   if (base + w3 <= (size_t)LDS_LIMIT) { *w3_off = (int)base; *total = base + w3; }
   else { *w3_off = -1; *total = base; }
 }
 
-template <int NW, bool SPLIT>
+template <int NW, int NTEAM, bool SPLIT>
 int launch_chain(ChainArgs a, int n_tiles, hipStream_t st) {
   size_t lds;
-  lds_plan<SPLIT>(a.dw.NT3, sizeof(ChainX), &a.w3_lds_off, &lds);
+  lds_plan<NTEAM, SPLIT>(a.dw.NT3, sizeof(ChainX), &a.w3_lds_off, &lds);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, SPLIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, SPLIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, NTEAM, SPLIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, NTEAM, SPLIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
     attr_done = true;
   }
-  if (a.w3_lds_off >= 0) hipLaunchKernelGGL((mh_chain_kernel<NW, SPLIT, true>), dim3(n_tiles), dim3(NW * 64), lds, st, a);
-  else                   hipLaunchKernelGGL((mh_chain_kernel<NW, SPLIT, false>), dim3(n_tiles), dim3(NW * 64), lds, st, a);
+  const dim3 blk(NW * NTEAM * 64);
+  if (a.w3_lds_off >= 0) hipLaunchKernelGGL((mh_chain_kernel<NW, NTEAM, SPLIT, true>), dim3(n_tiles), blk, lds, st, a);
+  else                   hipLaunchKernelGGL((mh_chain_kernel<NW, NTEAM, SPLIT, false>), dim3(n_tiles), blk, lds, st, a);
   return 0;
 }
 
-template <int NW, bool SPLIT, int MODE, int KP>
+template <int NW, int NTEAM, bool SPLIT, int MODE, int KP>
 void launch_decode_one(const DecodeArgs& a, int grid, size_t lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)decode_kernel<NW, SPLIT, true, MODE, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-    (void)hipFuncSetAttribute((const void*)decode_kernel<NW, SPLIT, false, MODE, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+    (void)hipFuncSetAttribute((const void*)decode_kernel<NW, NTEAM, SPLIT, true, MODE, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+    (void)hipFuncSetAttribute((const void*)decode_kernel<NW, NTEAM, SPLIT, false, MODE, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
     attr_done = true;
   }
-  if (a.w3_lds_off >= 0) hipLaunchKernelGGL((decode_kernel<NW, SPLIT, true, MODE, KP>), dim3(grid), dim3(NW * 64), lds, st, a);
-  else                   hipLaunchKernelGGL((decode_kernel<NW, SPLIT, false, MODE, KP>), dim3(grid), dim3(NW * 64), lds, st, a);
+  const dim3 blk(NW * NTEAM * 64);
+  if (a.w3_lds_off >= 0) hipLaunchKernelGGL((decode_kernel<NW, NTEAM, SPLIT, true, MODE, KP>), dim3(grid), blk, lds, st, a);
+  else                   hipLaunchKernelGGL((decode_kernel<NW, NTEAM, SPLIT, false, MODE, KP>), dim3(grid), blk, lds, st, a);
 }
-template <int NW, bool SPLIT, int MODE>
+template <int NW, int NTEAM, bool SPLIT, int MODE>
 int launch_decode_kp(DecodeArgs a, int Kp, int grid, hipStream_t st) {
   size_t lds;
-  lds_plan<SPLIT>(a.dw.NT3, sizeof(DecodeX), &a.w3_lds_off, &lds);
+  lds_plan<NTEAM, SPLIT>(a.dw.NT3, sizeof(DecodeX), &a.w3_lds_off, &lds);
   switch (Kp) {
-    case 8:  launch_decode_one<NW, SPLIT, MODE, 8>(a, grid, lds, st); break;
-    case 16: launch_decode_one<NW, SPLIT, MODE, 16>(a, grid, lds, st); break;
-    default: launch_decode_one<NW, SPLIT, MODE, 32>(a, grid, lds, st); break;
+    case 8:  launch_decode_one<NW, NTEAM, SPLIT, MODE, 8>(a, grid, lds, st); break;
+    case 16: launch_decode_one<NW, NTEAM, SPLIT, MODE, 16>(a, grid, lds, st); break;
+    default: launch_decode_one<NW, NTEAM, SPLIT, MODE, 32>(a, grid, lds, st); break;
   }
   return 0;
 }
 template <int MODE>
 int launch_decode(const vaenmf_plan* p, const DecodeArgs& a, hipStream_t st) {
-  const int grid = a.NT < p->n_sms * 4 ? a.NT : p->n_sms * 4;
+  const int want = p->n_sms * 2;                       // one 8-wave workgroup per CU is resident; 2 rounds
+  const int grid = a.NT < want ? a.NT : want;
   const bool split = p->cfg.precision == VAENMF_PREC_BF16X3;
   const int Kp = (MODE == MODE_STORE) ? 8 : p->Kp;
-  if (p->nwaves == 4) return split ? launch_decode_kp<4, true, MODE>(a, Kp, grid, st) : launch_decode_kp<4, false, MODE>(a, Kp, grid, st);
-  return split ? launch_decode_kp<8, true, MODE>(a, Kp, grid, st) : launch_decode_kp<8, false, MODE>(a, Kp, grid, st);
+  if (p->nwaves == 4) return split ? launch_decode_kp<4, 2, true, MODE>(a, Kp, grid, st) : launch_decode_kp<4, 2, false, MODE>(a, Kp, grid, st);
+  return split ? launch_decode_kp<8, 1, true, MODE>(a, Kp, grid, st) : launch_decode_kp<8, 1, false, MODE>(a, Kp, grid, st);
 }
 
 DecodeArgs base_decode_args(const vaenmf_plan* p, const float* Zs, int Rcap, int R, const float* B1) {
@@ -911,15 +945,15 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
   hipStream_t st = (hipStream_t)stream;
   const bool split = p->cfg.precision == VAENMF_PREC_BF16X3;
   ProfScope ps(p, VN_K_CHAIN, st);
-  if (p->nwaves == 4) { if (split) launch_chain<4, true>(a, p->n_tiles, st); else launch_chain<4, false>(a, p->n_tiles, st); }
-  else                { if (split) launch_chain<8, true>(a, p->n_tiles, st); else launch_chain<8, false>(a, p->n_tiles, st); }
+  if (p->nwaves == 4) { if (split) launch_chain<4, 2, true>(a, p->n_tiles, st); else launch_chain<4, 2, false>(a, p->n_tiles, st); }
+  else                { if (split) launch_chain<8, 1, true>(a, p->n_tiles, st); else launch_chain<8, 1, false>(a, p->n_tiles, st); }
   VN_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 extern "C" int vaenmf_rng_fill(vaenmf_plan* p, uint32_t call, int32_t S, float* eps_out, float* u_out, void* stream) {
   if (int e = check_bound(p)) return e;
-  hipLaunchKernelGGL(rng_fill_kernel, dim3(p->n_tiles), dim3(256), 0, (hipStream_t)stream, p->d_tile_utt, p->d_tile_n0,
+  hipLaunchKernelGGL(rng_fill_kernel, dim3(p->n_tiles), dim3(8 * p->tile_frames), 0, (hipStream_t)stream, p->d_tile_utt, p->d_tile_n0,
                      p->d_tile_cnt, p->d_frame_off, p->d_utt_seed, call, S, p->NT, eps_out, u_out);
   VN_CHECK_HIP(hipGetLastError());
   return 0;

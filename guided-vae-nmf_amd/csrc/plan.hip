@@ -81,6 +81,7 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   p->NT3 = p->Fs / 16;
   p->Kp = cfg->K <= 8 ? 8 : (cfg->K <= 16 ? 16 : 32);
   p->nwaves = p->NT3 <= 4 * MAXT ? 4 : 8;
+  p->tile_frames = p->nwaves == 4 ? 64 : 32;
   p->w1f = p->w2f = p->w3f = nullptr;
   p->b1 = p->b2 = p->b3 = p->w1y = nullptr;
   p->Dy = 0;
@@ -94,7 +95,7 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   VN_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
   p->n_sms = prop.multiProcessorCount;
   const size_t NTc = cfg->max_frames, Uc = cfg->max_utts;
-  const size_t max_tiles = NTc / FRAMES_PER_TILE + Uc + 1;
+  const size_t max_tiles = NTc / 32 + Uc + 1;
   int e = 0;
   e |= dev_alloc(&p->w1f, (size_t)(HID / 16) * 1 * 2 * 64 * 8);
   e |= dev_alloc(&p->w2f, (size_t)(HID / 16) * (HID / 32) * 2 * 64 * 8);
@@ -148,7 +149,7 @@ extern "C" int vaenmf_set_decoder_weights(vaenmf_plan* p, const float* W1, int32
   std::vector<uint16_t> f1 = pack_weights(W1, HID, LAT, in1, HID / 16, 1);
   std::vector<uint16_t> f2 = pack_weights(W2, HID, HID, HID, HID / 16, HID / 32);
   std::vector<uint16_t> f3 = pack_weights(W3, F, HID, HID, p->NT3, HID / 32);
-  std::vector<float> b3p(p->Fs, 0.f);
+  std::vector<float> b3p(p->Fs, -100.f);      // padding bins: W3 rows are 0, so Vs = exp(-100) ~ 0
   memcpy(b3p.data(), b3, sizeof(float) * F);
   int e = 0;
   e |= upload((uint16_t*)p->w1f, f1.data(), f1.size());
@@ -180,10 +181,10 @@ extern "C" int vaenmf_bind_batch(vaenmf_plan* p, int32_t n_utt, const int32_t* f
   for (int u = 0; u < n_utt; ++u) {
     const int b = frame_offsets[u], e = frame_offsets[u + 1];
     VN_REQUIRE(e > b, "utterance %d is empty", u);
-    for (int n = b; n < e; n += FRAMES_PER_TILE) {
+    for (int n = b; n < e; n += p->tile_frames) {
       t_utt.push_back(u);
       t_n0.push_back(n);
-      t_cnt.push_back(e - n < FRAMES_PER_TILE ? e - n : FRAMES_PER_TILE);
+      t_cnt.push_back(e - n < p->tile_frames ? e - n : p->tile_frames);
     }
     for (int n = b; n < e; ++n) { f_utt[n] = u; f_loc[n] = n - b; }
   }
