@@ -1,0 +1,171 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol that
+include/vaenmf.h declares, host logic (sharding, statistics, geometry, model containers,
+pickling, the M1 count quirk), and the drop-in import paths."""
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import vaenmf_oracle as orc
+from helpers import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import vaenmf
+    from vaenmf import _lib
+    hdr = open(os.path.join(ROOT, "include", "vaenmf.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vaenmf_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = _lib.lib()                       # loads libvaenmf.so; AttributeError if a bound symbol is missing
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.vaenmf_last_error() is not None
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without a GPU."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vaenmf.engine import BatchEngine
+    p = orc.xavier_normal_params([65, 32, [128, 128]], seed=0)
+    dec = [p["decoder.hidden.0.weight"], p["decoder.hidden.0.bias"], p["decoder.hidden.1.weight"],
+           p["decoder.hidden.1.bias"], p["decoder.reconstruction.weight"], p["decoder.reconstruction.bias"]]
+    with pytest.raises(RuntimeError):
+        BatchEngine(65, 4, dec)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "guided-vae-nmf_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "vaenmf_oracle" not in txt and "oracle/" not in txt, os.path.join(dirpath, f)
+
+
+def test_stft_geometry_host():
+    """stft.py:37-38 (integer window) and :48-53 (end-pad rule) on the host side of the C ABI."""
+    from vaenmf.stft import frame_geometry
+    assert frame_geometry(64000, 16000, 32e-3, 0.25) == (512, 128, 501, 64000)
+    nfft, hop, nfr, npad = frame_geometry(63000, 16000, 64e-3, 0.25)
+    X = orc.stft(np.zeros(63000), fs=16000, wlen_sec=64e-3)
+    assert (nfft, hop) == (1024, 256) and nfr == X.shape[1] and npad == 63000 + 256
+    for T in (16000, 16001, 40000, 64000, 70001, 99999):
+        for wl in (32e-3, 64e-3):
+            assert frame_geometry(T, 16000, wl, 0.25)[2] == orc.stft(np.zeros(T), fs=16000, wlen_sec=wl).shape[1]
+    with pytest.raises(ValueError):
+        frame_geometry(64000, 16000, 50.01e-3, 0.25)
+
+
+def test_shard_is_array_split():
+    """scripts/evaluate_M1.py:203: np.array_split(file_paths, nb_devices)."""
+    from vaenmf.pipeline import shard
+    files = ["f%03d" % i for i in range(27)]
+    for ws in (1, 2, 4, 8):
+        parts = [shard(files, ws, r) for r in range(ws)]
+        ref = [list(a) for a in np.array_split(files, ws)]
+        assert parts == ref and sum(parts, []) == files
+
+
+def test_metric_statistics():
+    """metrics.py:5-10, 70-108 from sufficient statistics == from the raw lists."""
+    from vaenmf import metrics as vm
+    g = np.random.default_rng(0)
+    vals = g.normal(3, 2, (50, 3))
+    snr = g.choice([-5.0, 0.0, 5.0], 50)
+    st = vm.sufficient_stats(vals, snr)
+    # splitting over two "ranks" and summing == all at once
+    st2 = vm.sufficient_stats(vals[:20], snr[:20]) + vm.sufficient_stats(vals[20:], snr[20:])
+    assert np.allclose(st, st2)
+    tab = vm.stats_table(st)
+    for k, key in enumerate(vm.METRIC_KEYS):
+        m, h = orc.mean_confidence_interval(vals[:, k])
+        assert tab[("all", key)][:2] == (m, h)
+        for b in (-5.0, 0.0, 5.0):
+            m, h = orc.mean_confidence_interval(vals[snr == b, k])
+            assert tab[("snr=%g" % b, key)][:2] == (m, h)
+    assert vm.mean_confidence_interval(vals[:, 0]) == orc.mean_confidence_interval(vals[:, 0])
+
+
+def test_ratios_from_gram_match_reference_formula():
+    from vaenmf import metrics as vm
+    z = np.load(GOLDEN + "/metrics_dummy_m2.npz")
+    sh, s, n = z["a_s_est"] / 32768.0, z["a_s"] / 32768.0, z["a_n"] / 32768.0
+    G = np.array([sh @ sh, sh @ s, sh @ n, s @ s, s @ n, n @ n])
+    assert np.allclose(vm.ratios_from_gram(G), z["a_ratios"], atol=1e-9)
+
+
+def test_synth_generators_equal_oracle_copies():
+    from vaenmf import synth
+    a, b = synth.synth_utterance(3, 8000), orc.synth_utterance(3, 8000)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    pa = synth.xavier_normal_params([65, 32, [128, 128]], seed=2, y_dim=1, bias_std=0.1)
+    pb = orc.xavier_normal_params([65, 32, [128, 128]], seed=2, y_dim=1, bias_std=0.1)
+    assert pa.keys() == pb.keys() and all(np.array_equal(pa[k], pb[k]) for k in pa)
+
+
+def test_model_containers_state_dict_layout():
+    """Key layout of SURVEY 5 / models.py so reference checkpoints load unchanged."""
+    import vaenmf
+    vae = vaenmf.VariationalAutoencoder([513, 32, [128, 128]])
+    keys = set(vae.state_dict())
+    assert keys == {"encoder.hidden.0.weight", "encoder.hidden.0.bias", "encoder.hidden.1.weight", "encoder.hidden.1.bias",
+                    "encoder.sample.mu.weight", "encoder.sample.mu.bias", "encoder.sample.log_var.weight",
+                    "encoder.sample.log_var.bias", "decoder.hidden.0.weight", "decoder.hidden.0.bias",
+                    "decoder.hidden.1.weight", "decoder.hidden.1.bias", "decoder.reconstruction.weight",
+                    "decoder.reconstruction.bias"}
+    assert vae.z_dim == 32 and float(vae.decoder.reconstruction.bias.abs().max()) == 0
+    dgm = vaenmf.DeepGenerativeModel([513, 1, 32, [128, 128]], None)
+    assert dgm.encoder.hidden[0].weight.shape == (128, 514) and dgm.decoder.hidden[0].weight.shape == (128, 33)
+    clf = vaenmf.Classifier([513, [128, 128], 1])
+    assert set(clf.state_dict()) == {"hidden.0.weight", "hidden.0.bias", "hidden.1.weight", "hidden.1.bias",
+                                     "output_layer.weight", "output_layer.bias"}
+    # forward == oracle on the same weights (plain torch forward of the container)
+    p = orc.xavier_normal_params([65, 32, [128, 128]], seed=1, bias_std=0.1)
+    v = vaenmf.VariationalAutoencoder([65, 32, [128, 128]])
+    v.load_state_dict({k: torch.tensor(x) for k, x in p.items()})
+    zin = np.random.default_rng(0).standard_normal((7, 32)).astype(np.float32)
+    with torch.no_grad():
+        out = v.decoder(torch.tensor(zin)).numpy()
+    assert np.max(np.abs(out / orc.decoder_forward(p, zin) - 1)) < 1e-5
+
+
+def test_mcem_objects_counts_and_pickle():
+    import vaenmf
+    m1 = vaenmf.MCEM_M1(niter=100)
+    assert (m1.e_step_counts(), m1.wf_counts()) == ((30, 30), (75, 30))       # the positional shift, mcem.py:461-462
+    q = np.load(GOLDEN + "/quirk_counts.npz")
+    (r, b), (rw, bw) = m1.e_step_counts(), m1.wf_counts()
+    assert (r + b, r, rw + bw, rw) == tuple(q["M1"])
+    m2 = vaenmf.MCEM_M2(niter=100)
+    (r, b), (rw, bw) = m2.e_step_counts(), m2.wf_counts()
+    assert (r + b, r, rw + bw, rw) == tuple(q["M2"])
+    assert vaenmf.MCEM_M1(niter=1, reference_compat=False).e_step_counts() == (10, 30)
+    m = pickle.loads(pickle.dumps(m1))                                          # spawn-Pool transport, evaluate_M1.py:206-216
+    assert m.niter == 100 and m.burnin_WF == 75
+
+
+def test_dropin_import_paths():
+    import importlib
+    import sys
+    pkg = os.path.join(ROOT, "guided-vae-nmf_amd")
+    assert pkg in sys.path
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "python" or k.startswith("python.")}
+    try:
+        mc = importlib.import_module("python.models.mcem")
+        md = importlib.import_module("python.models.models")
+        st = importlib.import_module("python.processing.stft")
+        me = importlib.import_module("python.metrics")
+        assert mc.MCEM_M1.__name__ == "MCEM_M1" and md.VariationalAutoencoder and st.stft and me.energy_ratios
+    finally:
+        for k in list(sys.modules):
+            if k == "python" or k.startswith("python."):
+                del sys.modules[k]
+        sys.modules.update(saved)
