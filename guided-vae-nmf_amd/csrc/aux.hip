@@ -5,26 +5,28 @@
 namespace {
 
 // ----------------------------------------------------------------------------
-// W update (mcem.py:107-110) + L1 column normalisation (mcem.py:129-133).
-// One workgroup per utterance: num[f,k] = sum_n P[n,f] H[k,n], den[f,k] = sum_n A1[n,f] H[k,n]
-// with P = X2 * sum_r Vx^-2 and A1 = sum_r Vx^-1 produced by decode_kernel<MODE_WSTATS>.
+// W update (mcem.py:107-110) + L1 column normalisation (mcem.py:129-133), two stages:
+//   w_partial_kernel: num[f,k] = sum_n P[n,f] H[k,n], den[f,k] = sum_n A1[n,f] H[k,n] over one of
+//                     NCH frame chunks of an utterance (P = X2 * sum_r Vx^-2, A1 = sum_r Vx^-1 come from
+//                     decode_kernel<MODE_WSTATS>); grid (NCH, U), one thread per bin
+//   w_update_kernel:  fixed-order sum of the NCH partials, W <- W sqrt(num/den), column norms
 // ----------------------------------------------------------------------------
+constexpr int W_NCH = 8;
+
 template <int KP>
-__global__ __launch_bounds__(1024) void w_update_kernel(const float* __restrict__ A1, const float* __restrict__ P,
-                                                        const float* __restrict__ Ht, float* __restrict__ W,
-                                                        float* __restrict__ normW, const int32_t* __restrict__ frame_off,
-                                                        int F, int Fs, int K, int FL, int NG) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);            // [FL][2*KP]
-  float* colred = red + (size_t)FL * 2 * KP;              // [32 waves][KP]
-  const int u = blockIdx.x;
-  const int f = threadIdx.x % FL, ng = threadIdx.x / FL;
+__global__ __launch_bounds__(640) void w_partial_kernel(const float* __restrict__ A1, const float* __restrict__ P,
+                                                        const float* __restrict__ Ht, float* __restrict__ part,
+                                                        const int32_t* __restrict__ frame_off, int Fs) {
+  const int u = blockIdx.y, ch = blockIdx.x, f = threadIdx.x;
   const int nb = frame_off[u], ne = frame_off[u + 1];
+  const int per = (ne - nb + W_NCH - 1) / W_NCH;
+  const int n0 = nb + ch * per, n1 = (n0 + per < ne) ? n0 + per : ne;
   float num[KP], den[KP];
 #pragma unroll
   for (int k = 0; k < KP; ++k) num[k] = den[k] = 0.f;
-  if (ng < NG && f < Fs) {
-    for (int n = nb + ng; n < ne; n += NG) {
+  if (f < Fs) {
+#pragma unroll 4
+    for (int n = n0; n < n1; ++n) {
       const float pv = P[(size_t)n * Fs + f], av = A1[(size_t)n * Fs + f];
 #pragma unroll
       for (int k = 0; k < KP; k += 4) {
@@ -33,55 +35,63 @@ __global__ __launch_bounds__(1024) void w_update_kernel(const float* __restrict_
         for (int t = 0; t < 4; ++t) { num[k + t] += pv * h[t]; den[k + t] += av * h[t]; }
       }
     }
-  }
-  // deterministic reduction over the NG frame groups (fixed order)
-  for (int r = 0; r < NG; ++r) {
-    if (ng == r && f < Fs) {
+    float* dst = part + (((size_t)u * W_NCH + ch) * Fs + f) * 2 * KP;
 #pragma unroll
-      for (int k = 0; k < KP; ++k) {
-        if (r == 0) { red[f * 2 * KP + 2 * k] = num[k]; red[f * 2 * KP + 2 * k + 1] = den[k]; }
-        else        { red[f * 2 * KP + 2 * k] += num[k]; red[f * 2 * KP + 2 * k + 1] += den[k]; }
-      }
+    for (int k = 0; k < KP; k += 4) {
+      *reinterpret_cast<f32x4*>(dst + k) = f32x4{num[k], num[k + 1], num[k + 2], num[k + 3]};
+      *reinterpret_cast<f32x4*>(dst + KP + k) = f32x4{den[k], den[k + 1], den[k + 2], den[k + 3]};
     }
-    __syncthreads();
   }
+}
+
+template <int KP>
+__global__ __launch_bounds__(640) void w_update_kernel(const float* __restrict__ part, float* __restrict__ W,
+                                                       float* __restrict__ normW, int F, int Fs, int K) {
+  __shared__ float colred[10][KP];
+  const int u = blockIdx.x, f = threadIdx.x;
   float wn[KP];
 #pragma unroll
   for (int k = 0; k < KP; ++k) wn[k] = 0.f;
-  if (ng == 0 && f < F) {
+  if (f < F) {
+    float num[KP], den[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) num[k] = den[k] = 0.f;
+    for (int ch = 0; ch < W_NCH; ++ch) {                 // fixed order: deterministic
+      const float* src = part + (((size_t)u * W_NCH + ch) * Fs + f) * 2 * KP;
+#pragma unroll
+      for (int k = 0; k < KP; k += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + k), b = *reinterpret_cast<const f32x4*>(src + KP + k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { num[k + t] += a[t]; den[k + t] += b[t]; }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < KP; ++k)
-      if (k < K) {
-        const float w0 = W[((size_t)u * Fs + f) * KP + k];
-        wn[k] = w0 * sqrtf(red[f * 2 * KP + 2 * k] / red[f * 2 * KP + 2 * k + 1]);     // mcem.py:110
-      }
+      if (k < K) wn[k] = W[((size_t)u * Fs + f) * KP + k] * sqrtf(num[k] / den[k]);          // mcem.py:110
   }
-  // column L1 norms (mcem.py:129): wave shuffle reduction, then across waves
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // column L1 norms (mcem.py:129): DPP/permlane wave sum, then across waves in fixed order
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
 #pragma unroll
   for (int k = 0; k < KP; ++k) {
-    float v = fabsf(wn[k]);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    if (lane == 0) colred[wv * KP + k] = v;
+    const float v = sum_rows4(sum_row16(fabsf(wn[k])));
+    if (lane == 0) colred[wv][k] = v;
   }
   __syncthreads();
-  const int nwv = blockDim.x >> 6;
   float nrm[KP];
 #pragma unroll
   for (int k = 0; k < KP; ++k) {
     float s = 0.f;
-    for (int ww = 0; ww < nwv; ++ww) s += colred[ww * KP + k];
+    for (int ww = 0; ww < nwv; ++ww) s += colred[ww][k];
     nrm[k] = s;
   }
-  if (ng == 0 && f < Fs) {
+  if (f < Fs) {
 #pragma unroll
     for (int k = 0; k < KP; ++k)
-      W[((size_t)u * Fs + f) * KP + k] = (k < K && f < F) ? wn[k] / nrm[k] : 0.f;        // mcem.py:131
+      W[((size_t)u * Fs + f) * KP + k] = (k < K && f < F) ? wn[k] / nrm[k] : 0.f;              // mcem.py:131
   }
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < KP; ++k) normW[(size_t)u * KP + k] = (k < K) ? nrm[k] : 0.f;    // applied to H (mcem.py:133)
+    for (int k = 0; k < KP; ++k) normW[(size_t)u * KP + k] = (k < K) ? nrm[k] : 0.f;         // applied to H (mcem.py:133)
   }
 }
 
@@ -298,17 +308,13 @@ int ilog2(int n) { int b = 0; while ((1 << b) < n) ++b; return b; }
 }  // namespace
 
 int vn_launch_w_update(const vaenmf_plan* p, float* W, const float* Ht, hipStream_t st) {
-  const int FL = ((p->Fs + 63) / 64) * 64;
-  int NG = 1024 / FL;
-  if (NG < 1) { vaenmf_set_error("Fs=%d too large for w_update", p->Fs); return -1; }
-  if (NG > 4) NG = 4;
-  const int threads = FL * NG;
-  const size_t lds = ((size_t)FL * 2 * p->Kp + 32 * p->Kp) * sizeof(float);
-#define VN_WU(KP)                                                                                              \
-  do {                                                                                                         \
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)w_update_kernel<KP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((w_update_kernel<KP>), dim3(p->n_utt), dim3(threads), lds, st, p->A1, p->P, Ht, W, p->normW, \
-                       p->d_frame_off, p->cfg.F, p->Fs, p->cfg.K, FL, NG);                                      \
+  const int threads = ((p->Fs + 63) / 64) * 64;        // one thread per bin (Fs <= 640)
+#define VN_WU(KP)                                                                                               \
+  do {                                                                                                          \
+    hipLaunchKernelGGL((w_partial_kernel<KP>), dim3(W_NCH, p->n_utt), dim3(threads), 0, st, p->A1, p->P, Ht,     \
+                       p->wpart, p->d_frame_off, p->Fs);                                                        \
+    hipLaunchKernelGGL((w_update_kernel<KP>), dim3(p->n_utt), dim3(threads), 0, st, p->wpart, W, p->normW,       \
+                       p->cfg.F, p->Fs, p->cfg.K);                                                               \
   } while (0)
   switch (p->Kp) { case 8: VN_WU(8); break; case 16: VN_WU(16); break; default: VN_WU(32); break; }
 #undef VN_WU

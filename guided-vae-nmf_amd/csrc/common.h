@@ -29,14 +29,15 @@ void vaenmf_set_error(const char* fmt, ...);
   } while (0)
 
 constexpr int MAX_TILE_FRAMES = 64;   // MH chain: frames per workgroup = 32 per team (2 MFMA column groups of 16)
-constexpr int MAXT = 5;               // feature tiles (16 bins each) per wave in the last layer
 constexpr int LAT = 32;               // latent dimension handled by the MFMA path
 constexpr int HID = 128;              // hidden width of both decoder layers
 
 struct vaenmf_plan {
   vaenmf_config cfg;
   int Fs, Kp, NT3;           // padded bins, padded rank, feature tiles of 16 in the last layer
-  int nwaves;                // waves of a team that split the features (4: F<=320, 8: F<=640)
+  int geom_dec;              // geometry of the decode kernels (same codes)
+  int geom;                  // workgroup geometry (engine.hip: launch_decode): 0 = 2x4 waves, 1 = 2x8, 2 = 1x8
+  int nwaves;                // waves of a team that split the features
   int tile_frames;           // MH-chain frames per workgroup: 64 (2 teams of 4 waves) or 32 (1 team of 8)
   // decoder weights on the device, MFMA fragment order (see weights in plan.hip)
   __bf16 *w1f, *w2f, *w3f;   // [tile][kstep][part hi/lo][lane][8]
@@ -55,6 +56,7 @@ struct vaenmf_plan {
   // workspace
   float *A1, *P;             // [NT][Fs] W-update statistics
   float* normW;              // [n_utt][Kp]
+  float* wpart;              // [n_utt][8 chunks][Fs][2 Kp] partial W-update sums
   double* cost_frames;       // [NT] (fused driver)
   int n_sms;
   // optional per-kernel timing with HIP events on the launch stream (vaenmf_profile_*)
@@ -96,6 +98,61 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
     lo[t] = (__bf16)(v[t] - (float)h);
   }
 }
+
+// ---- cross-lane sums without LDS traffic (DPP / permlane-swap VALU ops) ----------------
+// lane = 16 q + c: sum over c (the 16 lanes of a DPP row), over q (the 4 rows), or over the wave
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sum_row16(float v) {       // every lane gets the sum over its row
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);    // row_half_mirror
+  v += dpp_mov<0x140>(v);    // row_mirror
+  return v;
+}
+// v_permlane{16,32}_swap exchange halves between TWO registers; feeding one value twice lets
+// the compiler assign both operands the same register (a no-op swap), so the copy is made opaque.
+__device__ __forceinline__ unsigned opaque_copy(unsigned a) {
+  unsigned b = a;
+  asm volatile("" : "+v"(b));
+  return b;
+}
+__device__ __forceinline__ float swap16_add(float v) {      // v[l] + v[l ^ 16]
+  const unsigned a = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane16_swap(a, opaque_copy(a), false, false);
+  unsigned x = r[0], y = r[1];
+  asm volatile("" : "+v"(x), "+v"(y));      // keep both halves of the result (hipcc 7.2 folds r[1] into r[0] otherwise)
+  return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ float swap32_add(float v) {      // v[l] + v[l ^ 32]
+  const unsigned a = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(a, opaque_copy(a), false, false);
+  unsigned x = r[0], y = r[1];
+  asm volatile("" : "+v"(x), "+v"(y));
+  return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ float sum_rows4(float v) { return swap32_add(swap16_add(v)); }   // sum over q
+__device__ __forceinline__ double swap16_add_d(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+  auto rl = __builtin_amdgcn_permlane16_swap(lo, opaque_copy(lo), false, false);
+  auto rh = __builtin_amdgcn_permlane16_swap(hi, opaque_copy(hi), false, false);
+  const double a0 = __builtin_bit_cast(double, ((unsigned long long)rh[0] << 32) | rl[0]);
+  const double a1 = __builtin_bit_cast(double, ((unsigned long long)rh[1] << 32) | rl[1]);
+  return a0 + a1;
+}
+__device__ __forceinline__ double swap32_add_d(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+  auto rl = __builtin_amdgcn_permlane32_swap(lo, opaque_copy(lo), false, false);
+  auto rh = __builtin_amdgcn_permlane32_swap(hi, opaque_copy(hi), false, false);
+  const double a0 = __builtin_bit_cast(double, ((unsigned long long)rh[0] << 32) | rl[0]);
+  const double a1 = __builtin_bit_cast(double, ((unsigned long long)rh[1] << 32) | rl[1]);
+  return a0 + a1;
+}
+__device__ __forceinline__ double sum_rows4_d(double v) { return swap32_add_d(swap16_add_d(v)); }
 
 // xoshiro128+ : per-lane stream, 32 random bits per call, no multiplies
 struct Xs128 {

@@ -99,7 +99,7 @@ __device__ __forceinline__ void split8(const float (&z)[8], bf16x8& hi, bf16x8& 
 }
 
 // Everything a wave needs to run the decoder: LDS pointers + its (uniform) team / wave index.
-template <int NW, int NTEAM, bool SPLIT, bool W3LDS>
+template <int NW, int NTEAM, int MT, bool SPLIT, bool W3LDS>
 struct Dec {
   using M = LdsMap<NTEAM, SPLIT>;
   static constexpr int TPW = NT_H / NW;
@@ -197,14 +197,14 @@ struct Dec {
   // Last layer.  FLIP=false: acc[i][cg] rows = bins 16*tile+4q+t, cols = columns (frames);
   //              FLIP=true : acc[i][cg] rows = columns (samples) 4q+t, col = bin 16*tile+c.
   template <bool FLIP>
-  __device__ __forceinline__ void out_layer(f32x4 (&acc)[MAXT][2]) const {
+  __device__ __forceinline__ void out_layer(f32x4 (&acc)[MT][2]) const {
 #pragma unroll
     for (int s = 0; s < NK_H; ++s) {
       bf16x8 ahi[2], alo[2];
       act_frag(act2, 0, s, ahi[0], alo[0]);
       act_frag(act2, 1, s, ahi[1], alo[1]);
 #pragma unroll
-      for (int i = 0; i < MAXT; ++i) {
+      for (int i = 0; i < MT; ++i) {
         if (w + NW * i < NT3) {   // wave-uniform (w is an SGPR value)
           bf16x8 whi, wlo;
           w3_frag(i, s, whi, wlo);
@@ -219,14 +219,16 @@ struct Dec {
 };
 
 // workgroup prologue shared by both kernels: stage W1/W2 (and W3 when it fits), b2, b3 into LDS
-template <int NW, int NTEAM, bool SPLIT, bool W3LDS>
-__device__ __forceinline__ Dec<NW, NTEAM, SPLIT, W3LDS> dec_setup(char* smem, const DecW& dw, int w3_lds_off, int Fs) {
+template <int NW, int NTEAM, int MT, bool SPLIT, bool W3LDS>
+__device__ __forceinline__ Dec<NW, NTEAM, MT, SPLIT, W3LDS> dec_setup(char* smem, const DecW& dw, int w3_lds_off, int Fs) {
   using M = LdsMap<NTEAM, SPLIT>;
-  Dec<NW, NTEAM, SPLIT, W3LDS> d;
+  Dec<NW, NTEAM, MT, SPLIT, W3LDS> d;
   d.lds = smem;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   d.team = wid / NW;
-  d.w = wid - d.team * NW;
+  // logical wave index, rotated per team: waves w and w+NW share a SIMD, so the wave with one bin tile
+  // more than the others sits on a different SIMD in each team
+  d.w = (wid - d.team * NW + (NW / 2) * d.team) % NW;
   d.lane16 = (threadIdx.x & 63) * 16;
   d.NT3 = dw.NT3;
   d.act1 = smem + M::act + d.team * M::ACT_TEAM;
@@ -244,6 +246,18 @@ __device__ __forceinline__ Dec<NW, NTEAM, SPLIT, W3LDS> dec_setup(char* smem, co
 }
 
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
+
+// Diagnostic builds only (-DVN_STAMP): per-phase cycle sums of workgroup 0 / wave 0 into a debug buffer
+// that nothing else reads.  The shipped library never executes a stamp.
+#ifdef VN_STAMP
+__device__ long long* g_stamp_buf = nullptr;
+__device__ long long g_stamp_store[64];
+#define VN_STAMP_DECL long long _t_prev = (long long)__builtin_amdgcn_s_memtime(); const bool _st_on = blockIdx.x == 0 && threadIdx.x == 0;
+#define VN_STAMP_AT(slot) do { long long _t = (long long)__builtin_amdgcn_s_memtime(); if (_st_on) { g_stamp_store[slot] += _t - _t_prev; g_stamp_store[32 + slot] += 1; } _t_prev = _t; } while (0)
+#else
+#define VN_STAMP_DECL
+#define VN_STAMP_AT(slot)
+#endif
 
 // ============================================================================
 // MH chain (mcem.py:371-441 / :218-294)
@@ -268,13 +282,14 @@ struct ChainX {
   double epart[2][8][TEAM_COLS];
 };
 
-template <int NW, int NTEAM, bool SPLIT, bool W3LDS>
+template <int NW, int NTEAM, int MT, bool SPLIT, bool W3LDS>
 __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainArgs a) {
+  constexpr int MAXT = MT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using M = LdsMap<NTEAM, SPLIT>;
   constexpr int TPW = NT_H / NW;
   const DecW& dw = a.dw;
-  const Dec<NW, NTEAM, SPLIT, W3LDS> d = dec_setup<NW, NTEAM, SPLIT, W3LDS>(smem, dw, a.w3_lds_off, a.Fs);
+  const Dec<NW, NTEAM, MT, SPLIT, W3LDS> d = dec_setup<NW, NTEAM, MT, SPLIT, W3LDS>(smem, dw, a.w3_lds_off, a.Fs);
   ChainX& L = reinterpret_cast<ChainX*>(smem + M::common_end)[d.team];
   const int lane = threadIdx.x & 63, w = d.w, q = lane >> 4, c = lane & 15;
   const int tile = blockIdx.x;
@@ -409,8 +424,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
     ++ecount;
 #pragma unroll
     for (int fg = 0; fg < 2; ++fg) {
-      e[fg] += shfl_xor_d(e[fg], 16);
-      e[fg] += shfl_xor_d(e[fg], 32);
+      e[fg] = sum_rows4_d(e[fg]);
       if (q == 0) L.epart[par][w][16 * fg + c] = e[fg];
     }
     __syncthreads();
@@ -456,8 +470,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
         const float zn = z[fg][j] + sd * e8[fg][j];
         pr += z[fg][j] * z[fg][j] - zn * zn;
       }
-      pr += __shfl_xor(pr, 16, 64);
-      pr += __shfl_xor(pr, 32, 64);
+      pr = sum_rows4(pr);
       const float accp = (float)(Ecur[fg] - Ep[fg]) + 0.5f * pr;
       const float uu = fg == 0 ? uu0 : uu1;
       const bool ok = m < 0 || fast_log(uu) < accp;   // mcem.py:420
@@ -524,14 +537,15 @@ struct DecodeX {            // one per team
   double redC[8];
 };
 
-template <int NW, int NTEAM, bool SPLIT, bool W3LDS, int MODE, int KP>
+template <int NW, int NTEAM, int MT, bool SPLIT, bool W3LDS, int MODE, int KP>
 __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArgs a) {
+  constexpr int MAXT = MT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using M = LdsMap<NTEAM, SPLIT>;
   constexpr int TPW = NT_H / NW;
   constexpr int Kp = KP;
   const DecW& dw = a.dw;
-  const Dec<NW, NTEAM, SPLIT, W3LDS> d = dec_setup<NW, NTEAM, SPLIT, W3LDS>(smem, dw, a.w3_lds_off, a.Fs);
+  const Dec<NW, NTEAM, MT, SPLIT, W3LDS> d = dec_setup<NW, NTEAM, MT, SPLIT, W3LDS>(smem, dw, a.w3_lds_off, a.Fs);
   DecodeX& L = reinterpret_cast<DecodeX*>(smem + M::common_end)[d.team];
   const int lane = threadIdx.x & 63, w = d.w, q = lane >> 4, c = lane & 15;
   const int nch = (a.R + 31) / 32;
@@ -550,10 +564,68 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
   const int per = (a.NT + gridDim.x - 1) / gridDim.x;
   const int n_beg = blockIdx.x * per, n_end = (n_beg + per < a.NT) ? n_beg + per : a.NT;
 
+  // Inputs of one frame, loaded one iteration ahead so their HBM/L2 latency hides under the
+  // previous frame's decode (a team has nothing else to switch to while it waits).
+  struct FrameIn {
+    float zz[2][8];        // first 32 samples' latents, fragment order
+    float x2f[MT];
+    float hrow[KP];
+    float g;
+    int utt;
+  };
+  auto frame_of = [&](int nb, bool& on) {
+    on = nb + d.team < n_end;                   // team without a frame shadows the last one, stores masked
+    return on ? nb + d.team : n_end - 1;
+  };
+  auto load_z = [&](int n, int ch, float (&zz)[2][8]) {
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      int r = 32 * ch + 16 * sg + c;
+      r = r < a.R ? r : a.R - 1;
+      const float* src = a.Zs + ((size_t)n * a.Rcap + r) * LAT;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(src + 4 * q);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 16 + 4 * q);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { zz[sg][t] = lo[t]; zz[sg][4 + t] = hi[t]; }
+    }
+  };
+  auto load_frame = [&](int n, FrameIn& f) {
+    load_z(n, 0, f.zz);
+    f.utt = a.frame_utt[n];
+    if (MODE != MODE_STORE) {
+      f.g = a.g[n];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) f.x2f[i] = (w + NW * i < dw.NT3) ? a.X2[(size_t)n * a.Fs + fidx[i]] : 0.f;
+#pragma unroll
+      for (int k = 0; k < KP; k += 4) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f.hrow[k + t] = hv[t];
+      }
+    }
+  };
+  constexpr bool PREFETCH = !SPLIT;               // bf16x3 has no registers to spare for a second frame
+  FrameIn nxt;
+  if (PREFETCH) {
+    bool on0;
+    load_frame(frame_of(n_beg < n_end ? n_beg : 0, on0), nxt);
+  }
+  // rows of W of this lane's bins, cached per utterance when the rank is small (K <= 8)
+  constexpr bool WCACHE = (KP == 8) && !SPLIT;   // bf16x3 streams W3 hi+lo through registers: no room
+  float wreg[WCACHE ? MT : 1][KP];
+  int wutt = -1;
+
   for (int nb = n_beg; nb < n_end; nb += NTEAM) {
-    const bool on = nb + d.team < n_end;          // team without a frame shadows the last one, stores masked
-    const int n = on ? nb + d.team : n_end - 1;
-    const int utt = a.frame_utt[n];
+    bool on;
+    const int n = frame_of(nb, on);
+    if (!PREFETCH) load_frame(n, nxt);
+    const FrameIn cur = nxt;
+    if (PREFETCH && nb + NTEAM < n_end) {
+      bool on2;
+      load_frame(frame_of(nb + NTEAM, on2), nxt);
+    }
+    VN_STAMP_DECL
+    const int utt = cur.utt;
     f32x4 bias1[TPW][2];
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
@@ -565,15 +637,14 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
     // decode 32 samples (chunk ch) of frame n: vs[i][sg][t] = Vs(sample 32ch+16sg+4q+t, bin fidx[i])
     auto decode_chunk = [&](int ch, f32x4 (&vs)[MAXT][2]) {
       bf16x8 zhi[2], zlo[2];
-#pragma unroll
-      for (int sg = 0; sg < 2; ++sg) {
-        int r = 32 * ch + 16 * sg + c;
-        r = r < a.R ? r : a.R - 1;
-        const float* src = a.Zs + ((size_t)n * a.Rcap + r) * LAT;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(src + 4 * q);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 16 + 4 * q);
-        const float zz[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        split8<SPLIT>(zz, zhi[sg], zlo[sg]);
+      if (ch == 0) {
+        split8<SPLIT>(cur.zz[0], zhi[0], zlo[0]);
+        split8<SPLIT>(cur.zz[1], zhi[1], zlo[1]);
+      } else {
+        float zz[2][8];
+        load_z(n, ch, zz);
+        split8<SPLIT>(zz[0], zhi[0], zlo[0]);
+        split8<SPLIT>(zz[1], zhi[1], zlo[1]);
       }
       d.hidden(zhi, zlo, bias1, []() {});
 #pragma unroll
@@ -591,11 +662,13 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
           for (int t = 0; t < 4; ++t) vs[i][sg][t] = fast_exp(vs[i][sg][t]);
     };
     auto rvalid = [&](int ch, int sg, int t) { return 32 * ch + 16 * sg + 4 * q + t < a.R; };
-    auto sum_q = [&](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
-    auto sum_c = [&](float v) {
-      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-      return v;
-    };
+    auto sum_q = [&](float v) { return sum_rows4(v); };
+    auto sum_c = [&](float v) { return sum_row16(v); };
+    float mk[2][4];                    // 1 for real samples of chunk 0, 0 for the padding columns
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) mk[sg][t] = (16 * sg + 4 * q + t < a.R) ? 1.f : 0.f;
 
     if (MODE == MODE_STORE) {
       for (int ch = 0; ch < nch; ++ch) {
@@ -617,9 +690,22 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
     }
 
     // ---- per-bin constants of frame n: X2, rows of W, Vb = sum_k W[f,k] H[k,n]
-    const float gn = a.g[n];
+    const float gn = cur.g;
     float x2f[MAXT], vb[MAXT];
+    if (WCACHE && utt != wutt) {        // wave-uniform: all lanes of a team share the frame
+      wutt = utt;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int k = 0; k < Kp; k += 4) {
+          const f32x4 ww = (w + NW * i < dw.NT3) ? *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + fidx[i]) * Kp + k)
+                                                 : f32x4{0, 0, 0, 0};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) wreg[WCACHE ? i : 0][k + t] = ww[t];
+        }
+    }
     auto wrow = [&](int i, int k) {   // 4 consecutive ranks of W[utt][fidx[i]][:]
+      if (WCACHE) return f32x4{wreg[WCACHE ? i : 0][k], wreg[WCACHE ? i : 0][k + 1], wreg[WCACHE ? i : 0][k + 2], wreg[WCACHE ? i : 0][k + 3]};
       return *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + fidx[i]) * Kp + k);
     };
     auto dotWH = [&](int i, const float (&hvec)[KP]) {
@@ -634,16 +720,15 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
     float hs[KP];   // H[:,n] (MODE_HG: times the pending column norms of W)
 #pragma unroll
     for (int k = 0; k < Kp; k += 4) {
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * Kp + k);
       f32x4 nv = {1.f, 1.f, 1.f, 1.f};
       if (MODE == MODE_HG) nv = *reinterpret_cast<const f32x4*>(a.normW + (size_t)utt * Kp + k);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) hs[k + t] = hv[t] * nv[t];
+      for (int t = 0; t < 4; ++t) hs[k + t] = cur.hrow[k + t] * nv[t];
     }
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
       const bool tv = w + NW * i < dw.NT3;
-      x2f[i] = tv ? a.X2[(size_t)n * a.Fs + fidx[i]] : 0.f;
+      x2f[i] = cur.x2f[i];
       vb[i] = tv ? dotWH(i, hs) : 1.f;
     }
 
@@ -661,7 +746,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
           for (int sg = 0; sg < 2; ++sg)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-              const float r = rvalid(ch, sg, t) ? fast_rcp(gn * vs[i][sg][t] + vb[i]) : 0.f;
+              const float r = fast_rcp(gn * vs[i][sg][t] + vb[i]) * (ch == 0 ? mk[sg][t] : (rvalid(ch, sg, t) ? 1.f : 0.f));
               a1[i] += r;
               a2[i] += r * r;
             }
@@ -710,19 +795,23 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       }
     } else if (MODE == MODE_HG) {
       f32x4 vs[MAXT][2];
+      // chunk validity mask (chunk 0 uses mk; later chunks are rare: R > 32)
+      auto mask = [&](int ch, int sg, int t) { return ch == 0 ? mk[sg][t] : (rvalid(ch, sg, t) ? 1.f : 0.f); };
       // ---- H update (mcem.py:118-121): W already updated + normalised by w_update_kernel
       float a1[MAXT], a2[MAXT];
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) a1[i] = a2[i] = 0.f;
+      VN_STAMP_AT(0);
       for (int ch = 0; ch < nch; ++ch) {
         decode_chunk(ch, vs);
+        VN_STAMP_AT(1);
 #pragma unroll
         for (int i = 0; i < MAXT; ++i)
 #pragma unroll
           for (int sg = 0; sg < 2; ++sg)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-              const float r = rvalid(ch, sg, t) ? fast_rcp(gn * vs[i][sg][t] + vb[i]) : 0.f;
+              const float r = fast_rcp(gn * vs[i][sg][t] + vb[i]) * mask(ch, sg, t);
               a1[i] += r;
               a2[i] += r * r;
             }
@@ -733,6 +822,9 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
         a1[i] = fval[i] ? s1 : 0.f;
         a2[i] = fval[i] ? s2 * x2f[i] : 0.f;
       }
+      VN_STAMP_AT(2);
+      // num_k = sum_f W[f,k] X2 A2, den_k = sum_f W[f,k] A1: in-lane over this wave's bins, DPP row sum
+      // over the 16 bins of a tile, one LDS hop over the waves
       float nuk[KP], dek[KP];
 #pragma unroll
       for (int k = 0; k < Kp; ++k) nuk[k] = dek[k] = 0.f;
@@ -747,24 +839,36 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
           }
         }
 #pragma unroll
-      for (int k = 0; k < Kp; ++k) {
-        const float nu = sum_c(nuk[k]), de = sum_c(dek[k]);
-        if (lane == 0) { L.redH[w][2 * k] = nu; L.redH[w][2 * k + 1] = de; }
+      for (int k = 0; k < Kp; ++k) { nuk[k] = sum_c(nuk[k]); dek[k] = sum_c(dek[k]); }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < Kp; k += 4) {
+          *reinterpret_cast<f32x4*>(&L.redH[w][k]) = f32x4{nuk[k], nuk[k + 1], nuk[k + 2], nuk[k + 3]};
+          *reinterpret_cast<f32x4*>(&L.redH[w][32 + k]) = f32x4{dek[k], dek[k + 1], dek[k + 2], dek[k + 3]};
+        }
       }
+      VN_STAMP_AT(3);
       __syncthreads();
+      VN_STAMP_AT(4);
       float hn[KP];
 #pragma unroll
-      for (int k = 0; k < Kp; ++k) {
-        float nu = 0.f, de = 0.f;
+      for (int k = 0; k < Kp; k += 4) {
+        f32x4 nu = {0, 0, 0, 0}, de = {0, 0, 0, 0};
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) { nu += L.redH[ww][2 * k]; de += L.redH[ww][2 * k + 1]; }
-        hn[k] = (k < a.K) ? hs[k] * sqrtf(nu / de) : 0.f;
+        for (int ww = 0; ww < NW; ++ww) {
+          nu += *reinterpret_cast<const f32x4*>(&L.redH[ww][k]);
+          de += *reinterpret_cast<const f32x4*>(&L.redH[ww][32 + k]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          hn[k + t] = (k + t < a.K) ? hs[k + t] * __builtin_amdgcn_sqrtf(nu[t] * fast_rcp(de[t])) : 0.f;   // mcem.py:121
       }
       if (on && w == 0 && lane == 0) {
 #pragma unroll
         for (int k = 0; k < Kp; k += 4)
           *reinterpret_cast<f32x4*>(a.Ht + (size_t)n * Kp + k) = f32x4{hn[k], hn[k + 1], hn[k + 2], hn[k + 3]};
       }
+      VN_STAMP_AT(5);
       // ---- variances with the new W, H (mcem.py:124-125), then g update (mcem.py:138-142)
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) vb[i] = (w + NW * i < dw.NT3) ? dotWH(i, hn) : 1.f;
@@ -778,13 +882,13 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
 #pragma unroll
           for (int sg = 0; sg < 2; ++sg)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-              if (rvalid(ch, sg, t)) {
-                const float v = vs[i][sg][t];
-                const float r = fast_rcp(gn * v + vb[i]);
-                ng[i] += v * r * r;
-                dg[i] += v * r;
-              }
+            for (int t = 0; t < 4; ++t) {
+              const float v = vs[i][sg][t];
+              const float r = fast_rcp(gn * v + vb[i]) * mask(ch, sg, t);
+              const float vr = v * r;
+              dg[i] += vr;            // sum_r Vs / Vx
+              ng[i] += vr * r;        // sum_r Vs / Vx^2
+            }
       }
       float nu = 0.f, de = 0.f;
 #pragma unroll
@@ -794,34 +898,38 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       }
       nu = sum_c(nu);
       de = sum_c(de);
+      VN_STAMP_AT(6);
       if (lane == 0) { L.redG[w][0] = nu; L.redG[w][1] = de; }
       __syncthreads();
+      VN_STAMP_AT(7);
       nu = de = 0.f;
 #pragma unroll
       for (int ww = 0; ww < NW; ++ww) { nu += L.redG[ww][0]; de += L.redG[ww][1]; }
-      const float gnew = gn * sqrtf(nu / de);
+      const float gnew = gn * __builtin_amdgcn_sqrtf(nu * fast_rcp(de));          // mcem.py:142
       if (on && w == 0 && lane == 0) a.g[n] = gnew;
       // ---- cost (mcem.py:70) with the refreshed variances (mcem.py:151-152)
       float cs = 0.f;
       for (int ch = 0; ch < nch; ++ch) {
         if (nch > 1) decode_chunk(ch, vs);
 #pragma unroll
-        for (int i = 0; i < MAXT; ++i)
-          if (fval[i])
+        for (int i = 0; i < MAXT; ++i) {
+          float ci = 0.f;
 #pragma unroll
-            for (int sg = 0; sg < 2; ++sg)
+          for (int sg = 0; sg < 2; ++sg)
 #pragma unroll
-              for (int t = 0; t < 4; ++t)
-                if (rvalid(ch, sg, t)) {
-                  const float vx = gnew * vs[i][sg][t] + vb[i];
-                  cs += fast_log(vx) + x2f[i] * fast_rcp(vx);
-                }
+            for (int t = 0; t < 4; ++t) {
+              const float vx = gnew * vs[i][sg][t] + vb[i];
+              ci += (fast_log(vx) + x2f[i] * fast_rcp(vx)) * mask(ch, sg, t);
+            }
+          cs += fval[i] ? ci : 0.f;
+        }
       }
-      double cd = (double)cs;
-      cd += shfl_xor_d(cd, 1); cd += shfl_xor_d(cd, 2); cd += shfl_xor_d(cd, 4); cd += shfl_xor_d(cd, 8);
-      cd += shfl_xor_d(cd, 16); cd += shfl_xor_d(cd, 32);
+      // wave sum: rows in fp32 (DPP), then fp64 across the 4 rows and the waves
+      double cd = sum_rows4_d((double)sum_c(cs));
+      VN_STAMP_AT(8);
       if (lane == 0) L.redC[w] = cd;
       __syncthreads();
+      VN_STAMP_AT(9);
       if (on && w == 0 && lane == 0) {
         double s = 0.0;
         for (int ww = 0; ww < NW; ++ww) s += L.redC[ww];
@@ -858,53 +966,59 @@ void lds_plan(int NT3, size_t extra_per_team, int* w3_off, size_t* total) {
   else { *w3_off = -1; *total = base; }
 }
 
-template <int NW, int NTEAM, bool SPLIT>
+template <int NW, int NTEAM, int MT, bool SPLIT>
 int launch_chain(ChainArgs a, int n_tiles, hipStream_t st) {
   size_t lds;
   lds_plan<NTEAM, SPLIT>(a.dw.NT3, sizeof(ChainX), &a.w3_lds_off, &lds);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, NTEAM, SPLIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, NTEAM, SPLIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, NTEAM, MT, SPLIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, NTEAM, MT, SPLIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
     attr_done = true;
   }
   const dim3 blk(NW * NTEAM * 64);
-  if (a.w3_lds_off >= 0) hipLaunchKernelGGL((mh_chain_kernel<NW, NTEAM, SPLIT, true>), dim3(n_tiles), blk, lds, st, a);
-  else                   hipLaunchKernelGGL((mh_chain_kernel<NW, NTEAM, SPLIT, false>), dim3(n_tiles), blk, lds, st, a);
+  if (a.w3_lds_off >= 0) hipLaunchKernelGGL((mh_chain_kernel<NW, NTEAM, MT, SPLIT, true>), dim3(n_tiles), blk, lds, st, a);
+  else                   hipLaunchKernelGGL((mh_chain_kernel<NW, NTEAM, MT, SPLIT, false>), dim3(n_tiles), blk, lds, st, a);
   return 0;
 }
 
-template <int NW, int NTEAM, bool SPLIT, int MODE, int KP>
+template <int NW, int NTEAM, int MT, bool SPLIT, int MODE, int KP>
 void launch_decode_one(const DecodeArgs& a, int grid, size_t lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)decode_kernel<NW, NTEAM, SPLIT, true, MODE, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-    (void)hipFuncSetAttribute((const void*)decode_kernel<NW, NTEAM, SPLIT, false, MODE, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+    (void)hipFuncSetAttribute((const void*)decode_kernel<NW, NTEAM, MT, SPLIT, true, MODE, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+    (void)hipFuncSetAttribute((const void*)decode_kernel<NW, NTEAM, MT, SPLIT, false, MODE, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
     attr_done = true;
   }
   const dim3 blk(NW * NTEAM * 64);
-  if (a.w3_lds_off >= 0) hipLaunchKernelGGL((decode_kernel<NW, NTEAM, SPLIT, true, MODE, KP>), dim3(grid), blk, lds, st, a);
-  else                   hipLaunchKernelGGL((decode_kernel<NW, NTEAM, SPLIT, false, MODE, KP>), dim3(grid), blk, lds, st, a);
+  if (a.w3_lds_off >= 0) hipLaunchKernelGGL((decode_kernel<NW, NTEAM, MT, SPLIT, true, MODE, KP>), dim3(grid), blk, lds, st, a);
+  else                   hipLaunchKernelGGL((decode_kernel<NW, NTEAM, MT, SPLIT, false, MODE, KP>), dim3(grid), blk, lds, st, a);
 }
-template <int NW, int NTEAM, bool SPLIT, int MODE>
+template <int NW, int NTEAM, int MT, bool SPLIT, int MODE>
 int launch_decode_kp(DecodeArgs a, int Kp, int grid, hipStream_t st) {
   size_t lds;
   lds_plan<NTEAM, SPLIT>(a.dw.NT3, sizeof(DecodeX), &a.w3_lds_off, &lds);
   switch (Kp) {
-    case 8:  launch_decode_one<NW, NTEAM, SPLIT, MODE, 8>(a, grid, lds, st); break;
-    case 16: launch_decode_one<NW, NTEAM, SPLIT, MODE, 16>(a, grid, lds, st); break;
-    default: launch_decode_one<NW, NTEAM, SPLIT, MODE, 32>(a, grid, lds, st); break;
+    case 8:  launch_decode_one<NW, NTEAM, MT, SPLIT, MODE, 8>(a, grid, lds, st); break;
+    case 16: launch_decode_one<NW, NTEAM, MT, SPLIT, MODE, 16>(a, grid, lds, st); break;
+    default: launch_decode_one<NW, NTEAM, MT, SPLIT, MODE, 32>(a, grid, lds, st); break;
   }
   return 0;
 }
+// workgroup geometry: geom 0 = 2 teams x 4 waves (5 bin tiles per wave, F <= 320),
+//                     geom 1 = 2 teams x 8 waves (3 bin tiles per wave, F <= 384),
+//                     geom 2 = 1 team  x 8 waves (5 bin tiles per wave, F <= 640)
 template <int MODE>
 int launch_decode(const vaenmf_plan* p, const DecodeArgs& a, hipStream_t st) {
-  const int want = p->n_sms * 2;                       // one 8-wave workgroup per CU is resident; 2 rounds
+  const int want = p->n_sms * 2;
   const int grid = a.NT < want ? a.NT : want;
   const bool split = p->cfg.precision == VAENMF_PREC_BF16X3;
   const int Kp = (MODE == MODE_STORE) ? 8 : p->Kp;
-  if (p->nwaves == 4) return split ? launch_decode_kp<4, 2, true, MODE>(a, Kp, grid, st) : launch_decode_kp<4, 2, false, MODE>(a, Kp, grid, st);
-  return split ? launch_decode_kp<8, 1, true, MODE>(a, Kp, grid, st) : launch_decode_kp<8, 1, false, MODE>(a, Kp, grid, st);
+  switch (p->geom_dec) {
+    case 0: return split ? launch_decode_kp<4, 2, 5, true, MODE>(a, Kp, grid, st) : launch_decode_kp<4, 2, 5, false, MODE>(a, Kp, grid, st);
+    case 1: return split ? launch_decode_kp<8, 2, 3, true, MODE>(a, Kp, grid, st) : launch_decode_kp<8, 2, 3, false, MODE>(a, Kp, grid, st);
+    default: return split ? launch_decode_kp<8, 1, 5, true, MODE>(a, Kp, grid, st) : launch_decode_kp<8, 1, 5, false, MODE>(a, Kp, grid, st);
+  }
 }
 
 DecodeArgs base_decode_args(const vaenmf_plan* p, const float* Zs, int Rcap, int R, const float* B1) {
@@ -945,8 +1059,11 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
   hipStream_t st = (hipStream_t)stream;
   const bool split = p->cfg.precision == VAENMF_PREC_BF16X3;
   ProfScope ps(p, VN_K_CHAIN, st);
-  if (p->nwaves == 4) { if (split) launch_chain<4, 2, true>(a, p->n_tiles, st); else launch_chain<4, 2, false>(a, p->n_tiles, st); }
-  else                { if (split) launch_chain<8, 1, true>(a, p->n_tiles, st); else launch_chain<8, 1, false>(a, p->n_tiles, st); }
+  switch (p->geom) {
+    case 0: if (split) launch_chain<4, 2, 5, true>(a, p->n_tiles, st); else launch_chain<4, 2, 5, false>(a, p->n_tiles, st); break;
+    case 1: if (split) launch_chain<8, 2, 3, true>(a, p->n_tiles, st); else launch_chain<8, 2, 3, false>(a, p->n_tiles, st); break;
+    default: if (split) launch_chain<8, 1, 5, true>(a, p->n_tiles, st); else launch_chain<8, 1, 5, false>(a, p->n_tiles, st); break;
+  }
   VN_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1014,3 +1131,13 @@ extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* H
   if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, 0, B1, Zs, Rcap, nsWF, biWF, var_rw, &rng, nullptr, stream)) return e;
   return vaenmf_wiener(p, X2, W, Ht, g, Zs, Rcap, nsWF, B1, X, S_hat, N_hat, nullptr, nullptr, stream);
 }
+
+#ifdef VN_STAMP
+extern "C" int vaenmf_debug_stamps(long long* out64, int reset) {
+  long long h[64];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp_store), sizeof(h)) != hipSuccess) return -2;
+  for (int i = 0; i < 64; ++i) out64[i] = h[i];
+  if (reset) { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_store), z, sizeof(z)); }
+  return 0;
+}
+#endif

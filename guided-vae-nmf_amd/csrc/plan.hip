@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -70,7 +71,7 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   VN_REQUIRE(cfg && out, "null argument");
   VN_REQUIRE(cfg->L == LAT, "this build supports latent dim %d (got %d)", LAT, cfg->L);
   VN_REQUIRE(cfg->H1 == HID && cfg->H2 == HID, "this build supports hidden sizes %d,%d (got %d,%d)", HID, HID, cfg->H1, cfg->H2);
-  VN_REQUIRE(cfg->F >= 1 && cfg->F <= 16 * MAXT * 8, "F=%d out of range (1..%d)", cfg->F, 16 * MAXT * 8);
+  VN_REQUIRE(cfg->F >= 1 && cfg->F <= 640, "F=%d out of range (1..640)", cfg->F);
   VN_REQUIRE(cfg->K >= 1 && cfg->K <= 32, "NMF rank K=%d out of range (1..32)", cfg->K);
   VN_REQUIRE(cfg->max_frames >= 1 && cfg->max_utts >= 1, "bad capacities");
   VN_REQUIRE(cfg->precision == VAENMF_PREC_BF16X3 || cfg->precision == VAENMF_PREC_BF16, "bad precision");
@@ -80,8 +81,19 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   p->Fs = (cfg->F + 15) / 16 * 16;
   p->NT3 = p->Fs / 16;
   p->Kp = cfg->K <= 8 ? 8 : (cfg->K <= 16 ? 16 : 32);
-  p->nwaves = p->NT3 <= 4 * MAXT ? 4 : 8;
-  p->tile_frames = p->nwaves == 4 ? 64 : 32;
+  {
+    const char* g = getenv("VAENMF_GEOM");          // dev override (A/B runs)
+    // 2x4 waves (256 registers per wave: the X2/Vb tiles of the chain stay in registers) when F <= 320
+    int geom = p->NT3 <= 20 ? 0 : 2;
+    if (g && g[0] == '1' && p->NT3 <= 24) geom = 1;
+    if (g && g[0] == '2') geom = 2;
+    p->geom = geom;
+    p->geom_dec = p->NT3 <= 20 ? 0 : (p->NT3 <= 24 ? 1 : 2);
+    if (g && g[0] && g[1] == '1' && p->NT3 <= 24) p->geom_dec = 1;
+    if (g && g[0] && g[1] == '2') p->geom_dec = 2;
+    p->nwaves = geom == 0 ? 4 : 8;
+    p->tile_frames = geom == 2 ? 32 : 64;
+  }
   p->w1f = p->w2f = p->w3f = nullptr;
   p->b1 = p->b2 = p->b3 = p->w1y = nullptr;
   p->Dy = 0;
@@ -113,6 +125,7 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   e |= dev_alloc(&p->A1, NTc * p->Fs);
   e |= dev_alloc(&p->P, NTc * p->Fs);
   e |= dev_alloc(&p->normW, Uc * p->Kp);
+  e |= dev_alloc(&p->wpart, Uc * 8 * p->Fs * 2 * p->Kp);
   e |= dev_alloc(&p->cost_frames, NTc);
   if (e) { vaenmf_plan_destroy(p); return -2; }
   *out = p;
@@ -122,7 +135,7 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
 extern "C" void vaenmf_plan_destroy(vaenmf_plan* p) {
   if (!p) return;
   void* ptrs[] = {p->w1f, p->w2f, p->w3f, p->b1, p->b2, p->b3, p->w1y, p->d_frame_off, p->d_tile_utt, p->d_tile_n0,
-                  p->d_tile_cnt, p->d_frame_utt, p->d_frame_loc, p->d_utt_seed, p->A1, p->P, p->normW, p->cost_frames};
+                  p->d_tile_cnt, p->d_frame_utt, p->d_frame_loc, p->d_utt_seed, p->A1, p->P, p->normW, p->wpart, p->cost_frames};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
