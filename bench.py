@@ -7,8 +7,10 @@ GPU: waveforms resident in HBM -> STFT -> |X|^2 -> encoder -> 100 x (MH E-step, 
 metric statistics over ranks (the job's only collective).  Workload at N=1 =
 BASELINE.json configs[1]: 64 utterances x 4 s @16 kHz, 512-pt STFT (F=257, 501 frames
 each), M1, NMF rank 8, 100 EM iterations, reference-faithful MH counts (60/30 per
-E-step, 105/75 for the Wiener chain), decoder GEMMs on bf16 MFMA.  For N>1 every rank
-runs its own 64-utterance shard (weak scaling; utterances are independent).
+E-step, 105/75 for the Wiener chain), decoder GEMMs on bf16 MFMA (fp32 accumulate; `--precision bf16x3`
+selects the 3-term split mode used for the tight parity tests, also timed once and reported as
+"parity_mode").  For N>1 every rank runs its own 64-utterance shard (weak scaling; utterances
+are independent).
 
 Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).
 """
@@ -75,7 +77,9 @@ def main():
     ap.add_argument("--niter", type=int, default=100)
     ap.add_argument("--nfft", type=int, default=512)
     ap.add_argument("--rank-k", type=int, default=8)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16x3", "bf16"],
+                    help="decoder MFMA mode: bf16 (BASELINE config 2) or bf16x3 (3-term split, ~fp32 accuracy)")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra bf16x3 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -145,6 +149,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # the same step in the bf16x3 (parity-grade) mode, one timed step, for the record
+    par = None
+    if args.precision == "bf16" and not args.no_parity_mode and world == 1:
+        del rec
+        torch.cuda.empty_cache()
+        rec3 = Reconstructor(params, F, args.rank_k, niter=args.niter, model="M1", reference_compat=True, fs=fs,
+                             wlen_sec=wlen, precision="bf16x3", device=dev, max_frames=U * 520, max_utts=U)
+        rec3.enhance(wav_x, counts, seeds=[u for u in ids], init_seed=0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rec3.enhance(wav_x, counts, seeds=[7 + u for u in ids], init_seed=1)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter() - t1
+        par = {"dtype": "bf16x3", "value": U * rec3.frame_counts[0] / t3, "unit": "frames/s", "ms_per_step": t3 * 1e3}
+        rec = rec3
     if rank == 0:
         frames_per_utt = rec.frame_counts[0]
         frames = U * frames_per_utt * world * args.steps
@@ -158,6 +177,14 @@ def main():
         n_w = args.steps
         flops_chain_avg = flop_row * (rows_e * n_e + rows_w * n_w) / max(n_e + n_w, 1)
         achieved = flops_chain_avg / (chain_ms * 1e-3) / 1e12 if chain_ms > 0 else 0.0
+        # HBM bytes of the chain kernel per launch from the committed rocprofv3 PMC passes of this command
+        # (profiles/round1_<precision>_traffic.json; collected with scripts_dev/profile.sh), else null
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "round1_%s_traffic.json" % args.precision)))
+            traffic = [v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items() if k.startswith("mh_chain_kernel")][0]
+        except Exception:
+            pass
         kernels = {k: {"ms_total": round(ms[i], 3), "launches": int(cn[i])}
                    for i, k in enumerate(["mh_chain", "decode_wstats", "w_update", "decode_hg", "decode_wiener"])}
         out = {
@@ -171,7 +198,7 @@ def main():
                                    % (U, nfft, F, frames_per_utt, args.rank_k, args.niter, nsE + biE, nsE, nsW + biW, nsW),
                        "utterances_per_gpu": U, "parallelism": "utterance-shard x%d" % world},
             "roofline": {"bound": "mfma", "kernel": "mh_chain_kernel", "achieved": achieved, "peak": PEAK_BF16_DENSE / 1e12,
-                         "unit": "TFLOP/s", "frac": achieved * 1e12 / PEAK_BF16_DENSE, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved * 1e12 / PEAK_BF16_DENSE, "traffic": traffic,
                          "avg_launch_ms": chain_ms,
                          "note": "algorithmic decoder flops (1 proposal decode per MH step, %d flop/row); the bf16x3 mode "
                                  "issues 3 MFMAs per algorithmic product" % flop_row},
@@ -184,6 +211,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(F, frames_per_utt, args.rank_k, args.niter)
+        if par is not None:
+            out["parity_mode"] = par
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
