@@ -111,6 +111,10 @@ struct Dec {
   int w, team, NT3;
   unsigned lane16;
 
+  // Teams run in lockstep through workgroup barriers.  (A per-team LDS-counter barrier was tried:
+  // decoupling the teams did not pay -- mh_chain 0.62 -> 0.68 ms per launch -- so it was dropped.)
+  __device__ __forceinline__ void team_sync() const { __syncthreads(); }
+
   static __device__ __forceinline__ int act_off(int cg, int s) { return (cg * NK_H + s) * M::PARTS * 1024; }
 
   __device__ __forceinline__ void lds_w(int base, int tile, int nk, int s, bf16x8& hi, bf16x8& lo) const {
@@ -164,7 +168,7 @@ struct Dec {
 #pragma unroll
       for (int cg = 0; cg < 2; ++cg) store_act(act1, cg, tile, mma3<SPLIT>(whi, wlo, zhi[cg], zlo[cg], bias1[ti][cg]));
     }
-    __syncthreads();
+    team_sync();
     between();
     f32x4 acc2[TPW][2];
     const float* b2 = reinterpret_cast<const float*>(lds + M::b2);
@@ -186,12 +190,12 @@ struct Dec {
         for (int cg = 0; cg < 2; ++cg) acc2[ti][cg] = mma3<SPLIT>(whi, wlo, ahi[cg], alo[cg], acc2[ti][cg]);
       }
     }
-    if (M::ALIAS) __syncthreads();      // every wave is done reading the layer-1 image
+    if (M::ALIAS) team_sync();      // every wave is done reading the layer-1 image
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti)
 #pragma unroll
       for (int cg = 0; cg < 2; ++cg) store_act(act2, cg, w + NW * ti, acc2[ti][cg]);
-    __syncthreads();
+    team_sync();
   }
 
   // Last layer.  FLIP=false: acc[i][cg] rows = bins 16*tile+4q+t, cols = columns (frames);
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
       e[fg] = sum_rows4_d(e[fg]);
       if (q == 0) L.epart[par][w][16 * fg + c] = e[fg];
     }
-    __syncthreads();
+    d.team_sync();
 #pragma unroll
     for (int fg = 0; fg < 2; ++fg) {
       double s = 0.0;
@@ -534,7 +538,7 @@ struct DecodeArgs {
 struct DecodeX {            // one per team
   float redH[8][64];        // [wave][2*Kp]
   float redG[8][2];
-  double redC[8];
+  double redC[2][8];        // [iteration parity][wave]
 };
 
 template <int NW, int NTEAM, int MT, bool SPLIT, bool W3LDS, int MODE, int KP>
@@ -605,6 +609,9 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
     }
   };
   constexpr bool PREFETCH = !SPLIT;               // bf16x3 has no registers to spare for a second frame
+  f32x4 bias1_m1[TPW];                             // M1: the layer-1 bias is the same for every frame
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti) bias1_m1[ti] = *reinterpret_cast<const f32x4*>(dw.b1 + 16 * (w + NW * ti) + 4 * q);
   FrameIn nxt;
   if (PREFETCH) {
     bool on0;
@@ -615,6 +622,15 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
   float wreg[WCACHE ? MT : 1][KP];
   int wutt = -1;
 
+  int pend_n = -1, pend_par = 0, cpar = 0;        // MODE_HG: frame whose cost partials wait in LDS
+  auto finish_cost = [&]() {
+    if (MODE == MODE_HG && pend_n >= 0 && w == 0 && lane == 0) {
+      double s = 0.0;
+      for (int ww = 0; ww < NW; ++ww) s += L.redC[pend_par][ww];
+      a.cost_frames[pend_n] = s;
+    }
+    pend_n = -1;
+  };
   for (int nb = n_beg; nb < n_end; nb += NTEAM) {
     bool on;
     const int n = frame_of(nb, on);
@@ -629,9 +645,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
     f32x4 bias1[TPW][2];
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
-      const int f0 = 16 * (w + NW * ti) + 4 * q;
-      bias1[ti][0] = a.B1 ? *reinterpret_cast<const f32x4*>(a.B1 + (size_t)n * HID + f0)
-                          : *reinterpret_cast<const f32x4*>(dw.b1 + f0);
+      bias1[ti][0] = a.B1 ? *reinterpret_cast<const f32x4*>(a.B1 + (size_t)n * HID + 16 * (w + NW * ti) + 4 * q) : bias1_m1[ti];
       bias1[ti][1] = bias1[ti][0];
     }
     // decode 32 samples (chunk ch) of frame n: vs[i][sg][t] = Vs(sample 32ch+16sg+4q+t, bin fidx[i])
@@ -848,8 +862,9 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
         }
       }
       VN_STAMP_AT(3);
-      __syncthreads();
+      d.team_sync();
       VN_STAMP_AT(4);
+      finish_cost();
       float hn[KP];
 #pragma unroll
       for (int k = 0; k < Kp; k += 4) {
@@ -900,7 +915,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       de = sum_c(de);
       VN_STAMP_AT(6);
       if (lane == 0) { L.redG[w][0] = nu; L.redG[w][1] = de; }
-      __syncthreads();
+      d.team_sync();
       VN_STAMP_AT(7);
       nu = de = 0.f;
 #pragma unroll
@@ -927,15 +942,18 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       // wave sum: rows in fp32 (DPP), then fp64 across the 4 rows and the waves
       double cd = sum_rows4_d((double)sum_c(cs));
       VN_STAMP_AT(8);
-      if (lane == 0) L.redC[w] = cd;
-      __syncthreads();
+      // the cross-wave sum of the cost is finished one iteration later (after that iteration's first
+      // barrier) so that this reduction costs no barrier of its own
+      if (lane == 0) L.redC[cpar][w] = cd;
+      pend_n = on ? n : -1;
+      pend_par = cpar;
+      cpar ^= 1;
       VN_STAMP_AT(9);
-      if (on && w == 0 && lane == 0) {
-        double s = 0.0;
-        for (int ww = 0; ww < NW; ++ww) s += L.redC[ww];
-        a.cost_frames[n] = s;
-      }
     }
+  }
+  if (MODE == MODE_HG) {
+    d.team_sync();
+    finish_cost();
   }
 }
 
