@@ -318,3 +318,78 @@ def test_stft_istft_and_metrics():
         vstft.stft(x, fs=16000, wlen_sec=50.01e-3)
     r = vmet.energy_ratios(zz["a_s_est"] / 32768.0, zz["a_s"] / 32768.0, zz["a_n"] / 32768.0)
     assert np.allclose(r, zz["a_ratios"], atol=1e-6)
+
+
+@pytest.mark.parametrize("F,K,R,model", [(513, 10, 30, "M1"), (513, 32, 10, "M2"), (257, 32, 30, "M1"), (129, 16, 40, "M1")])
+def test_m_step_and_chain_other_shapes(F, K, R, model):
+    """M-step (mcem.py:90-152) + cost + one MH chain + Wiener filter at the shapes the golden runs do not
+    cover: F=513 (n_fft 1024, the reference scripts' STFT; one team of 8 waves), NMF rank 10 (the scripts'
+    default), 16 and 32 (padded-rank code paths), R > 32 (chunked sample decode), ragged batch of 3."""
+    need_gpu()
+    Dy = 1 if model == "M2" else 0
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=7, y_dim=Dy, bias_std=0.05)
+    counts = [21, 40, 9]
+    g = np.random.default_rng(F + K)
+    Xs = [((g.standard_normal((n, F)) + 1j * g.standard_normal((n, F))) * (0.5 + 3 * np.exp(-np.arange(F) / 60.0))).astype(np.complex64) for n in counts]
+    W0 = [np.maximum(g.random((F, K)), 1e-8).astype(np.float32) for _ in counts]
+    H0 = [np.maximum(g.random((K, n)), 1e-8).astype(np.float32) for n in counts]
+    ys = [(g.random((n, Dy)) > 0.5).astype(np.float32) for n in counts] if Dy else [None] * 3
+    eng = make_engine(params, F, K, counts, Rcap=R)
+    eng.set_spectrogram(Xs)
+    eng.init_nmf(W0, H0)
+    if Dy:
+        eng.set_labels(torch.from_numpy(np.concatenate(ys)))
+    NT = sum(counts)
+    Zs = (0.7 * g.standard_normal((NT, R, 32))).astype(np.float32)
+    gains = (0.5 + g.random(NT)).astype(np.float32)
+    eng.Zs.copy_(torch.from_numpy(Zs))
+    eng.g.copy_(torch.from_numpy(gains))
+    # oracle objects per utterance, driven from the same state
+    oracles = []
+    for u, n in enumerate(counts):
+        o = orc.MCEMOracle(model, 1)
+        o.init_parameters(Xs[u], params, K, 1e-8, orc.NumpyRNG(0), y=ys[u], W0=W0[u], H0=H0[u])
+        sl = eng.utt_slice(u)
+        o.g = gains[sl].copy()
+        o.compute_Vs(Zs[sl]); o.compute_Vs_scaled(); o.compute_Vx()
+        oracles.append(o)
+    # Wiener filter from the same samples (before the update)
+    S, Nn, WFs, WFn = eng.wiener(R, want_masks=True)
+    for u, o in enumerate(oracles):
+        ws, wn = o.compute_WF(sample=False)
+        sl = eng.utt_slice(u)
+        assert rel_err(WFs[sl, :F].cpu().numpy().T, ws) < 5e-4 and rel_err(WFn[sl, :F].cpu().numpy().T, wn) < 5e-4
+    eng.m_step(R)
+    cost = eng.cost_from_frames(R)
+    for u, o in enumerate(oracles):
+        o.M_step()
+        sl = eng.utt_slice(u)
+        assert rel_err(eng.W[u, :F, :K].cpu().numpy(), o.W) < 1e-3
+        assert rel_err(eng.Ht[sl, :K].cpu().numpy().T, o.H) < 1e-3
+        assert rel_err(eng.g[sl].cpu().numpy(), o.g) < 1e-3
+        assert abs(cost[u] - o.compute_expected_neg_log_like()) / abs(cost[u]) < 2e-4
+    assert float(eng.W[:, F:].abs().max() if eng.Fs > F else 0) == 0
+    assert float(eng.Ht[:, K:].abs().max() if eng.Kp > K else 0) == 0
+    # one replayed MH chain from this state: log-acceptances against the oracle
+    S_steps, ns = 6, 3
+    eps = g.standard_normal((S_steps, NT, 32)).astype(np.float32)
+    uu = g.random((S_steps, NT)).astype(np.float32)
+    Z0 = (0.5 * g.standard_normal((NT, 32))).astype(np.float32)
+    eng.Z.copy_(torch.from_numpy(Z0))
+    acc = eng.mh_chain(ns, S_steps - ns, 0.01, eps=torch.from_numpy(eps).to(eng.device), u=torch.from_numpy(uu).to(eng.device),
+                       want_acc=True).cpu().numpy()
+    for u, o in enumerate(oracles):
+        sl = eng.utt_slice(u)
+        o.W = eng.W[u, :F, :K].cpu().numpy(); o.H = eng.Ht[sl, :K].cpu().numpy().T.copy(); o.g = eng.g[sl].cpu().numpy()
+        o.compute_Vb()
+        draws = []
+        for m in range(S_steps):
+            draws += [eps[m, sl].T.copy(), uu[m, sl].copy()]
+        o.rng = orc.ReplayRNG(draws)
+        tr = []
+        Zs_ref = o.sample_posterior(Z0[sl].T.copy(), ns, S_steps - ns, trace=tr)
+        ref_acc = np.stack([t["acc"] for t in tr])
+        margin = np.abs(np.log(uu[:, sl]) - ref_acc)
+        assert np.max(np.abs(acc[:, sl] - ref_acc)) < 3e-3
+        if margin.min() > 1e-2:                     # decisions are only comparable away from the threshold
+            assert np.max(np.abs(eng.Zs[sl, :ns].cpu().numpy() - Zs_ref)) < 1e-5
