@@ -81,6 +81,8 @@ def main():
                     help="decoder MFMA mode: bf16 (BASELINE config 2) or bf16x3 (3-term split, ~fp32 accuracy)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra bf16x3 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="M1", choices=["M1", "M2vad", "M2ibm"],
+                    help="M1 (BASELINE config 2, default) or the guided M2 variants of config 3 (labels from a classifier)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,13 +116,20 @@ def main():
     to_dev = lambda l: torch.from_numpy(np.concatenate(l).astype(np.float32)).to(dev)
     wav_x, wav_s, wav_n = to_dev(wav_x), to_dev(wav_s), to_dev(wav_n)
     counts = [T] * U
-    params = xavier_normal_params([F, 32, [128, 128]], seed=0)
-    rec = Reconstructor(params, F, args.rank_k, niter=args.niter, model="M1", reference_compat=True, fs=fs,
+    Dy = {"M1": 0, "M2vad": 1, "M2ibm": F}[args.model]
+    params = xavier_normal_params([F, 32, [128, 128]], seed=0, y_dim=Dy)
+    clf = None
+    if Dy:
+        from vaenmf.synth import xavier_normal_classifier
+        cp = xavier_normal_classifier([F, [128, 128], Dy], seed=1)
+        clf = [(cp["hidden.0.weight"], cp["hidden.0.bias"]), (cp["hidden.1.weight"], cp["hidden.1.bias"]),
+               (cp["output_layer.weight"], cp["output_layer.bias"])]
+    rec = Reconstructor(params, F, args.rank_k, niter=args.niter, model="M1" if not Dy else "M2", reference_compat=True, fs=fs,
                         wlen_sec=wlen, precision=args.precision, device=dev, max_frames=U * 520, max_utts=U)
     nsE, biE, nsW, biW = rec.nsE, rec.biE, rec.nsW, rec.biW
 
     def step(i):
-        s_hat, n_hat, cost = rec.enhance(wav_x, counts, seeds=[1000 * i + u for u in ids], init_seed=i)
+        s_hat, n_hat, cost = rec.enhance(wav_x, counts, seeds=[1000 * i + u for u in ids], init_seed=i, classifier=clf)
         G = vmet.gram3_batch(s_hat, wav_s, wav_n, counts)          # D2H of 6 doubles per utterance
         r = np.stack(vmet.ratios_from_gram(G), 1)
         st = allreduce_stats(vmet.sufficient_stats(r, snr), dev)   # RCCL all-reduce (<1 KB)
@@ -151,7 +160,7 @@ def main():
 
     # the same step in the bf16x3 (parity-grade) mode, one timed step, for the record
     par = None
-    if args.precision == "bf16" and not args.no_parity_mode and world == 1:
+    if args.precision == "bf16" and not args.no_parity_mode and world == 1 and not Dy:
         del rec
         torch.cuda.empty_cache()
         rec3 = Reconstructor(params, F, args.rank_k, niter=args.niter, model="M1", reference_compat=True, fs=fs,
@@ -193,9 +202,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3 (bf16 MFMA, 3-term hi/lo split, fp32 accumulate)" if args.precision == "bf16x3" else "bf16",
             "data": "synthetic",
-            "config": {"workload": "%d-utterance batch per GPU, M1 reconstruct, %d-pt STFT (F=%d, %d frames/utt), "
-                                   "NMF rank %d, %d EM iters, MH %d/%d per E-step + %d/%d Wiener chain"
-                                   % (U, nfft, F, frames_per_utt, args.rank_k, args.niter, nsE + biE, nsE, nsW + biW, nsW),
+            "config": {"workload": ("%d-utterance batch per GPU, %s reconstruct, %d-pt STFT (F=%d, %d frames/utt), "
+                                    "NMF rank %d, %d EM iters, MH %d/%d per E-step + %d/%d Wiener chain")
+                                   % (U, args.model, nfft, F, frames_per_utt, args.rank_k, args.niter, nsE + biE, nsE, nsW + biW, nsW),
                        "utterances_per_gpu": U, "parallelism": "utterance-shard x%d" % world},
             "roofline": {"bound": "mfma", "kernel": "mh_chain_kernel", "achieved": achieved, "peak": PEAK_BF16_DENSE / 1e12,
                          "unit": "TFLOP/s", "frac": achieved * 1e12 / PEAK_BF16_DENSE, "traffic": traffic,

@@ -121,6 +121,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case VAENMF_ACT_TANH: return tanhf(v);
     case VAENMF_ACT_RELU: return fmaxf(v, 0.f);
     case VAENMF_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case VAENMF_ACT_STEP: return v > 0.f ? 1.f : 0.f;
     default: return v;
   }
 }

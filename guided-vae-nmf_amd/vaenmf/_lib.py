@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libvaenmf.so")
 PREC_BF16X3, PREC_BF16 = 0, 1
 RNG_REPLAY, RNG_DEVICE = 0, 1
 Q_FS, Q_KP, Q_TILES, Q_NT, Q_NUTT = 0, 1, 2, 3, 4
-ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID, ACT_STEP = 0, 1, 2, 3, 4
 
 
 class Config(C.Structure):

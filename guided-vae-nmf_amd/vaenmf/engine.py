@@ -144,6 +144,24 @@ class BatchEngine:
         w, b = enc[-1]
         self.Z.copy_(self.dense(h, t(w), t(b), _lib.ACT_NONE))
 
+    def classify(self, clf, mean=None, std=None, eps=1e-8):
+        """Labels from the classifier (scripts/evaluate_M2_vad.py:122-131): optional mean/std
+        normalisation of |X|^2 (folded into the first layer on the host), ReLU hidden layers,
+        sigmoid output, hard threshold 0.5.  clf = [(W,b) hidden..., (W,b) output] float32 numpy;
+        mean/std numpy (F,1).  Returns (y_soft, y_hard) device float32 [NT,Dy]."""
+        t = lambda a: torch.from_numpy(_np32(a)).to(self.device)
+        layers = [(np.asarray(w, np.float64), np.asarray(b, np.float64)) for w, b in clf]
+        if mean is not None:
+            m = np.asarray(mean, np.float64).reshape(-1)
+            s = np.asarray(std, np.float64).reshape(-1) + eps
+            w0, b0 = layers[0]
+            layers[0] = (w0 / s[None, :], b0 - (w0 / s[None, :]) @ m)
+        h = self.X2[:, :self.F]
+        for (w, b) in layers[:-1]:
+            h = self.dense(h, t(w), t(b), _lib.ACT_RELU)
+        w, b = layers[-1]
+        return self.dense(h, t(w), t(b), _lib.ACT_SIGMOID), self.dense(h, t(w), t(b), _lib.ACT_STEP)
+
     def set_labels(self, y):
         """y device float32 [NT,Dy]: fold the label half of the first decoder layer."""
         if self.Dy == 0:

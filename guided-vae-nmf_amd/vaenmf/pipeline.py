@@ -36,8 +36,10 @@ class Reconstructor:
                                max_frames=max_frames, max_utts=max_utts)
         self.model = model
 
-    def enhance(self, wav, sample_counts, seeds=None, init_seed=0, y=None):
-        """wav: device float32 [sum T].  Returns (s_hat, n_hat) device float32 [sum T], cost [U,niter] (device)."""
+    def enhance(self, wav, sample_counts, seeds=None, init_seed=0, y=None, classifier=None, mean=None, std=None):
+        """wav: device float32 [sum T].  Returns (s_hat, n_hat) device float32 [sum T], cost [U,niter] (device).
+        M2: give the labels `y` (device [NT,Dy]) or a classifier [(W,b)...] (+ optional mean/std, (F,1)):
+        labels = classifier(normalised |X|^2) > 0.5 as in scripts/evaluate_M2_vad.py:122-131."""
         eng = self.eng
         X, fc = vstft.stft_batch(wav, sample_counts, self.fs, self.wlen_sec, self.hop_percent, Fs=eng.Fs, device=self.device)
         eng.bind(fc, Rcap=max(self.nsE, self.nsW), seeds=seeds)
@@ -50,6 +52,8 @@ class Reconstructor:
         eng.Ht.zero_()
         eng.Ht[:, :self.K] = torch.rand(eng.NT, self.K, device=self.device, generator=gen).clamp_min(self.eps)
         eng.g.fill_(1.0)
+        if classifier is not None:
+            self.y_soft, y = eng.classify(classifier, mean, std, self.eps)
         if y is not None:
             eng.set_labels(y)
         eng.encode(self.enc, y)

@@ -49,3 +49,19 @@ def xavier_normal_params(dims, seed=0, y_dim=0, bias_std=0.0):
         p["decoder.hidden.%d.weight" % (i - 1)], p["decoder.hidden.%d.bias" % (i - 1)] = lin(dec[i], dec[i - 1])
     p["decoder.reconstruction.weight"], p["decoder.reconstruction.bias"] = lin(x_dim, dec[-1])
     return p
+
+
+def xavier_normal_classifier(dims, seed=0, bias_std=0.0):
+    """Classifier([x_dim, h_dim, y_dim]) key layout (python/models/models.py:44-55)."""
+    x_dim, h_dim, y_dim = dims
+    g = np.random.default_rng(seed)
+    p = {}
+    neurons = [x_dim, *h_dim]
+    for i in range(1, len(neurons)):
+        std = math.sqrt(2.0 / (neurons[i] + neurons[i - 1]))
+        p["hidden.%d.weight" % (i - 1)] = (g.standard_normal((neurons[i], neurons[i - 1])) * std).astype(np.float32)
+        p["hidden.%d.bias" % (i - 1)] = (g.standard_normal(neurons[i]) * bias_std).astype(np.float32)
+    std = math.sqrt(2.0 / (h_dim[-1] + y_dim))
+    p["output_layer.weight"] = (g.standard_normal((y_dim, h_dim[-1])) * std).astype(np.float32)
+    p["output_layer.bias"] = (g.standard_normal(y_dim) * bias_std).astype(np.float32)
+    return p

@@ -53,7 +53,8 @@ enum { VAENMF_RNG_REPLAY = 0,    /* caller supplies the normal / uniform draws (
 
 enum { VAENMF_Q_FS = 0, VAENMF_Q_KP = 1, VAENMF_Q_TILES = 2, VAENMF_Q_NT = 3, VAENMF_Q_NUTT = 4 };
 
-enum { VAENMF_ACT_NONE = 0, VAENMF_ACT_TANH = 1, VAENMF_ACT_RELU = 2, VAENMF_ACT_SIGMOID = 3 };
+enum { VAENMF_ACT_NONE = 0, VAENMF_ACT_TANH = 1, VAENMF_ACT_RELU = 2, VAENMF_ACT_SIGMOID = 3,
+       VAENMF_ACT_STEP = 4 };   /* 1 if x > 0 else 0: sigmoid(x) > 0.5, scripts/evaluate_M2_vad.py:131 */
 
 typedef struct {
   int32_t F;          /* frequency bins, n_fft/2+1 (<= 640)                         */

@@ -393,3 +393,34 @@ def test_m_step_and_chain_other_shapes(F, K, R, model):
         assert np.max(np.abs(acc[:, sl] - ref_acc)) < 3e-3
         if margin.min() > 1e-2:                     # decisions are only comparable away from the threshold
             assert np.max(np.abs(eng.Zs[sl, :ns].cpu().numpy() - Zs_ref)) < 1e-5
+
+
+def test_classifier_labels():
+    """scripts/evaluate_M2_vad.py:122-131: (x-mean^T)/(std+eps)^T -> Classifier -> > 0.5."""
+    need_gpu()
+    F, Dy = 129, 5
+    z = np.load(GOLDEN + "/mlp_forward.npz")
+    cp = {k.split(":p:")[1]: z[k] for k in z.files if k.startswith("clf:p:")}
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=3, y_dim=Dy)
+    counts = [11, 30]
+    g = np.random.default_rng(2)
+    Xs = [(g.standard_normal((n, F)) + 1j * g.standard_normal((n, F))).astype(np.complex64) for n in counts]
+    eng = make_engine(params, F, 4, counts, Rcap=4)
+    eng.set_spectrogram(Xs)
+    clf = [(cp["hidden.0.weight"], cp["hidden.0.bias"]), (cp["hidden.1.weight"], cp["hidden.1.bias"]),
+           (cp["output_layer.weight"], cp["output_layer.bias"])]
+    mean = g.random((F, 1)).astype(np.float32) * 2
+    std = (0.5 + g.random((F, 1))).astype(np.float32)
+    x_pow = np.concatenate([np.abs(x) ** 2 for x in Xs]).astype(np.float32)
+    for mm, ss in ((None, None), (mean, std)):
+        soft, hard = eng.classify(clf, mm, ss)
+        rs, rh = orc.classifier_labels(cp, x_pow, mm, ss)
+        assert np.max(np.abs(soft.cpu().numpy() - rs)) < 2e-5
+        sure = np.abs(rs - 0.5) > 1e-4
+        assert np.array_equal(hard.cpu().numpy()[sure], rh[sure])
+    # golden forward of the reference Classifier itself
+    eng2 = make_engine(params, F, 4, [z["clf_x"].shape[0]], Rcap=4)
+    y = eng2.dense(torch.from_numpy(z["clf_x"]).to(eng2.device), *[torch.from_numpy(a).to(eng2.device) for a in clf[0]], 2)
+    y = eng2.dense(y, *[torch.from_numpy(a).to(eng2.device) for a in clf[1]], 2)
+    y = eng2.dense(y, *[torch.from_numpy(a).to(eng2.device) for a in clf[2]], 3)
+    assert np.max(np.abs(y.cpu().numpy() - z["clf_y"])) < 1e-5
