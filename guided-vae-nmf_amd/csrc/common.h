@@ -34,9 +34,10 @@ constexpr int HID = 128;              // hidden width of both decoder layers
 
 struct vaenmf_plan {
   vaenmf_config cfg;
-  int Fs, Kp, NT3;           // padded bins, padded rank, feature tiles of 16 in the last layer
-  int geom_dec;              // geometry of the decode kernels (same codes)
-  int geom;                  // workgroup geometry (engine.hip: launch_decode): 0 = 2x4 waves, 1 = 2x8, 2 = 1x8
+  int Fs, Kp, NT3;           // padded bins, padded rank, feature tiles of 16 on the MFMA path of the last layer
+  int Fm;                    // bins on the MFMA path: F-1 when F = 16k+1 (the odd last bin is computed in fp32 FMA), else F
+  float* w3n;                // [HID] fp32 row F-1 of the last layer (odd last bin)
+  int geom;                  // workgroup geometry (engine.hip: launch_decode)
   int nwaves;                // waves of a team that split the features
   int tile_frames;           // MH-chain frames per workgroup: 64 (2 teams of 4 waves) or 32 (1 team of 8)
   // decoder weights on the device, MFMA fragment order (see weights in plan.hip)

@@ -26,8 +26,11 @@ constexpr int TEAM_COLS = 32;      // MLP input rows ("columns") per team and pa
 struct DecW {                      // decoder weights (device), fragment order [tile][kstep][part][lane][8]
   const __bf16 *w1f, *w2f, *w3f;
   const float *b1, *b2, *b3;
-  int NT3;                         // feature tiles in the last layer
-  int F;
+  const float* w3n;                // fp32 row F-1 of the last layer when the odd last bin is off the tiles
+  int NT3;                         // feature tiles in the last layer (MFMA path)
+  int F;                           // bins
+  int Fm;                          // bins on the MFMA path: F-1 when F = 16k+1 (n_fft/2+1: the Nyquist bin would
+                                   // cost a whole 16-row tile, a fifth of one wave's work), else F
 };
 
 // A workgroup = NTEAM teams x NW waves.  The NW waves of a team split the output features of
@@ -53,7 +56,8 @@ struct LdsMap {
   static constexpr int w2 = w1 + W1B;
   static constexpr int b2 = w2 + W2B;              // float[HID]
   static constexpr int b3 = b2 + HID * 4;          // float[640]
-  static constexpr int common_end = b3 + 640 * 4;
+  static constexpr int nyq = b3 + 640 * 4;         // float[NTEAM][8 waves][2 col groups][16]: partial logits of the odd last bin
+  static constexpr int common_end = nyq + NTEAM * 8 * 2 * 16 * 4;
   static __host__ __device__ constexpr int w3_bytes(int NT3) { return NT3 * NK_H * PARTS * 1024; }
 };
 
@@ -110,6 +114,9 @@ struct Dec {
   const char* w3l;      // LDS W3 fragments                                                  [W3LDS]
   int w, team, NT3;
   unsigned lane16;
+  bool nyq;             // the odd last bin is computed beside the tiles
+  f32x4 wn[NT_H / NW];  // its weights for this lane's hidden features (rows 4q+t of this wave's layer-2 tiles)
+  float* nyqbuf;        // this team's [wave][col group][16] partial sums in LDS
 
   // Teams run in lockstep through workgroup barriers.  (A per-team LDS-counter barrier was tried:
   // decoupling the teams did not pay -- mh_chain 0.62 -> 0.68 ms per launch -- so it was dropped.)
@@ -138,11 +145,8 @@ struct Dec {
     hi = *reinterpret_cast<const bf16x8*>(p);
     if (SPLIT) lo = *reinterpret_cast<const bf16x8*>(p + 1024); else lo = hi;
   }
-  // tanh + split + store one accumulator tile (feature tile `tile`) into an LDS image
-  __device__ __forceinline__ void store_act(char* img, int cg, int tile, f32x4 acc) const {
-    f32x4 h;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) h[t] = fast_tanh(acc[t]);
+  // split + store one tile of activations (feature tile `tile`, already tanh'ed) into an LDS image
+  __device__ __forceinline__ void store_h(char* img, int cg, int tile, const f32x4 h) const {
     const int s = tile >> 1, e = tile & 1;
     bf16x4 hi, lo;
 #pragma unroll
@@ -153,6 +157,20 @@ struct Dec {
     }
     *reinterpret_cast<bf16x4*>(img + act_off(cg, s) + lane16 + e * 8) = hi;
     if (SPLIT) *reinterpret_cast<bf16x4*>(img + act_off(cg, s) + 1024 + lane16 + e * 8) = lo;
+  }
+  static __device__ __forceinline__ f32x4 tanh4(const f32x4 a) {
+    f32x4 h;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h[t] = fast_tanh(a[t]);
+    return h;
+  }
+  __device__ __forceinline__ void store_act(char* img, int cg, int tile, f32x4 acc) const { store_h(img, cg, tile, tanh4(acc)); }
+  // logit of the odd last bin for column (cg, lane&15): sum of the waves' partial dot products + bias
+  __device__ __forceinline__ float nyq_logit(int cg, float bias) const {
+    float a = bias;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) a += nyqbuf[(ww * 2 + cg) * 16 + ((lane16 >> 4) & 15)];
+    return a;
   }
 
   // Hidden layers 1 and 2 for this team's two column groups.  zhi/zlo: layer-1 B fragments
@@ -191,10 +209,22 @@ struct Dec {
       }
     }
     if (M::ALIAS) team_sync();      // every wave is done reading the layer-1 image
+    float pn[2] = {0.f, 0.f};
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti)
 #pragma unroll
-      for (int cg = 0; cg < 2; ++cg) store_act(act2, cg, w + NW * ti, acc2[ti][cg]);
+      for (int cg = 0; cg < 2; ++cg) {
+        const f32x4 h = tanh4(acc2[ti][cg]);
+        store_h(act2, cg, w + NW * ti, h);
+        pn[cg] += h[0] * wn[ti][0] + h[1] * wn[ti][1] + h[2] * wn[ti][2] + h[3] * wn[ti][3];
+      }
+    if (nyq) {           // fp32 partial dot of the odd last bin over this wave's hidden features
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg) {
+        const float v = sum_rows4(pn[cg]);
+        if ((lane16 >> 8) == 0) nyqbuf[(w * 2 + cg) * 16 + ((lane16 >> 4) & 15)] = v;
+      }
+    }
     team_sync();
   }
 
@@ -239,6 +269,11 @@ __device__ __forceinline__ Dec<NW, NTEAM, MT, SPLIT, W3LDS> dec_setup(char* smem
   d.act2 = M::ALIAS ? d.act1 : d.act1 + M::ACT;
   d.w3g = reinterpret_cast<const char*>(dw.w3f) + (size_t)d.w * NK_H * 2 * 1024;
   d.w3l = smem + (W3LDS ? w3_lds_off : 0);
+  d.nyq = dw.Fm != dw.F;
+  d.nyqbuf = reinterpret_cast<float*>(smem + M::nyq) + d.team * 8 * 2 * 16;
+#pragma unroll
+  for (int ti = 0; ti < NT_H / NW; ++ti)
+    d.wn[ti] = d.nyq ? *reinterpret_cast<const f32x4*>(dw.w3n + 16 * (d.w + NW * ti) + 4 * ((threadIdx.x & 63) >> 4)) : f32x4{0, 0, 0, 0};
   stage_weights<M::PARTS>(smem + M::w1, dw.w1f, NT_H);
   stage_weights<M::PARTS>(smem + M::w2, dw.w2f, NT_H * NK_H);
   if (W3LDS) stage_weights<M::PARTS>(smem + w3_lds_off, dw.w3f, dw.NT3 * NK_H);
@@ -340,9 +375,20 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        if (f0 + t >= dw.F) { xv[t] = 0.f; v[t] = 1.f; }
+        if (f0 + t >= dw.Fm) { xv[t] = 0.f; v[t] = 1.f; }
       x2[i][fg] = xv;
       vb[i][fg] = v;
+    }
+  }
+  // ---- the odd last bin (F = 16k+1), column-on-lane: constants of frame (fg, c)
+  float x2n[2] = {0.f, 0.f}, vbn[2] = {1.f, 1.f};
+  if (d.nyq) {
+#pragma unroll
+    for (int fg = 0; fg < 2; ++fg) {
+      x2n[fg] = a.X2[(size_t)nrow[fg] * a.Fs + dw.F - 1];
+      float v = 0.f;
+      for (int k = 0; k < a.Kp; ++k) v += a.W[((size_t)utt * a.Fs + dw.F - 1) * a.Kp + k] * a.Ht[(size_t)nrow[fg] * a.Kp + k];
+      vbn[fg] = v;
     }
   }
   // ---- layer-1 accumulator init: b1, or per frame b1 + W1y y_n (M2, folded by vaenmf_layer1_bias)
@@ -422,6 +468,16 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
           }
           e[fg] += (double)part;
         }
+      }
+    }
+    if (d.nyq) {
+      const float bn = b3l[dw.F - 1];
+#pragma unroll
+      for (int fg = 0; fg < 2; ++fg) {
+        const float vs = fast_exp(d.nyq_logit(fg, bn));
+        const float vx = gn[fg] * vs + vbn[fg];
+        const float term = fast_log(vx) + x2n[fg] * fast_rcp(vx);
+        e[fg] += (w == 0 && q == 0) ? (double)term : 0.0;        // counted once per frame
       }
     }
     const int par = ecount & 1;
@@ -562,7 +618,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
   for (int i = 0; i < MAXT; ++i) {
     const int t16 = w + NW * i;
     fidx[i] = 16 * t16 + c;
-    fval[i] = t16 < dw.NT3 && fidx[i] < dw.F;
+    fval[i] = t16 < dw.NT3 && fidx[i] < dw.Fm;
   }
   // contiguous chunk of frames per workgroup; the teams take alternate frames of the chunk
   const int per = (a.NT + gridDim.x - 1) / gridDim.x;
@@ -575,6 +631,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
     float x2f[MT];
     float hrow[KP];
     float g;
+    float x2n;             // X2 of the odd last bin
     int utt;
   };
   auto frame_of = [&](int nb, bool& on) {
@@ -598,6 +655,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
     f.utt = a.frame_utt[n];
     if (MODE != MODE_STORE) {
       f.g = a.g[n];
+      f.x2n = d.nyq ? a.X2[(size_t)n * a.Fs + dw.F - 1] : 0.f;
 #pragma unroll
       for (int i = 0; i < MT; ++i) f.x2f[i] = (w + NW * i < dw.NT3) ? a.X2[(size_t)n * a.Fs + fidx[i]] : 0.f;
 #pragma unroll
@@ -618,7 +676,8 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
     load_frame(frame_of(n_beg < n_end ? n_beg : 0, on0), nxt);
   }
   // rows of W of this lane's bins, cached per utterance when the rank is small (K <= 8)
-  constexpr bool WCACHE = (KP == 8) && !SPLIT;   // bf16x3 streams W3 hi+lo through registers: no room
+  // register budget: bf16x3 streams W3 hi+lo through registers and MODE_HG keeps all sample variances: no room
+  constexpr bool WCACHE = (KP == 8) && !SPLIT && MODE != MODE_HG;
   float wreg[WCACHE ? MT : 1][KP];
   int wutt = -1;
 
@@ -649,6 +708,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       bias1[ti][1] = bias1[ti][0];
     }
     // decode 32 samples (chunk ch) of frame n: vs[i][sg][t] = Vs(sample 32ch+16sg+4q+t, bin fidx[i])
+    float vsn[2] = {0.f, 0.f}, mkn[2] = {0.f, 0.f};   // odd last bin, column-on-lane: Vs and validity of sample (sg, c)
     auto decode_chunk = [&](int ch, f32x4 (&vs)[MAXT][2]) {
       bf16x8 zhi[2], zlo[2];
       if (ch == 0) {
@@ -667,6 +727,14 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
         vs[i][0] = f32x4{bv, bv, bv, bv};
         vs[i][1] = vs[i][0];
       }
+      if (d.nyq) {
+        const float bn = b3l[dw.F - 1];
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+          vsn[sg] = fast_exp(d.nyq_logit(sg, bn));
+          mkn[sg] = (32 * ch + 16 * sg + c < a.R) ? 1.f : 0.f;
+        }
+      }
       d.template out_layer<true>(vs);
 #pragma unroll
       for (int i = 0; i < MAXT; ++i)
@@ -675,6 +743,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
 #pragma unroll
           for (int t = 0; t < 4; ++t) vs[i][sg][t] = fast_exp(vs[i][sg][t]);
     };
+    const bool lead = w == 0 && lane == 0;            // the one lane that books the odd last bin
     auto rvalid = [&](int ch, int sg, int t) { return 32 * ch + 16 * sg + 4 * q + t < a.R; };
     auto sum_q = [&](float v) { return sum_rows4(v); };
     auto sum_c = [&](float v) { return sum_row16(v); };
@@ -698,6 +767,14 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
                 for (int t = 0; t < 4; ++t)
                   if (rvalid(ch, sg, t))
                     a.Vs_out[((size_t)n * a.R + 32 * ch + 16 * sg + 4 * q + t) * a.Fs + fidx[i]] = fval[i] ? vs[i][sg][t] : 0.f;
+          if (d.nyq && w == 0 && q == 0)
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+              if (mkn[sg] != 0.f) {
+                float* row = a.Vs_out + ((size_t)n * a.R + 32 * ch + 16 * sg + c) * a.Fs;
+                row[dw.F - 1] = vsn[sg];
+                for (int f = dw.F; f < a.Fs; ++f) row[f] = 0.f;       // padding bins
+              }
         }
       }
       continue;
@@ -746,9 +823,22 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       vb[i] = tv ? dotWH(i, hs) : 1.f;
     }
 
+    // W[utt][F-1][:] (odd last bin), re-read at its three uses (same address in every lane: one L1 line)
+    auto wn4 = [&](int k) { return *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + dw.F - 1) * Kp + k); };
+    float vbn = 1.f;
+    const float x2n = cur.x2n;
+    if (d.nyq) {
+      vbn = 0.f;
+#pragma unroll
+      for (int k = 0; k < Kp; k += 4) {
+        const f32x4 ww = wn4(k);
+        vbn += ww[0] * hs[k] + ww[1] * hs[k + 1] + ww[2] * hs[k + 2] + ww[3] * hs[k + 3];
+      }
+    }
+
     if (MODE == MODE_WSTATS) {
       // A1 = sum_r 1/Vx, A2 = sum_r 1/Vx^2 with the pre-update variances (mcem.py:107-109)
-      float a1[MAXT], a2[MAXT];
+      float a1[MAXT], a2[MAXT], a1n = 0.f, a2n = 0.f;
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) a1[i] = a2[i] = 0.f;
       for (int ch = 0; ch < nch; ++ch) {
@@ -764,6 +854,12 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
               a1[i] += r;
               a2[i] += r * r;
             }
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+          const float r = fast_rcp(gn * vsn[sg] + vbn) * mkn[sg];
+          a1n += r;
+          a2n += r * r;
+        }
       }
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
@@ -773,9 +869,16 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
           a.P[(size_t)n * a.Fs + fidx[i]] = fval[i] ? x2f[i] * s2 : 0.f;
         }
       }
+      if (d.nyq) {
+        const float s1 = sum_c(a1n), s2 = sum_c(a2n);
+        if (on && w == 0 && q == 0 && dw.F - 1 + c < a.Fs) {       // lane 0: the bin; lanes 1..: zero the padding
+          a.A1[(size_t)n * a.Fs + dw.F - 1 + c] = c == 0 ? s1 : 0.f;
+          a.P[(size_t)n * a.Fs + dw.F - 1 + c] = c == 0 ? x2n * s2 : 0.f;
+        }
+      }
     } else if (MODE == MODE_WF) {
       // WFs = mean_r(g Vs / Vx), WFn = mean_r(Vb / Vx)  (mcem.py:486-488)
-      float ws[MAXT], wn[MAXT];
+      float ws[MAXT], wn[MAXT], wsn = 0.f, wnn = 0.f;
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) ws[i] = wn[i] = 0.f;
       for (int ch = 0; ch < nch; ++ch) {
@@ -793,8 +896,27 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
                 ws[i] += sc * r;
                 wn[i] += vb[i] * r;
               }
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+          const float sc = gn * vsn[sg];
+          const float r = fast_rcp(sc + vbn) * mkn[sg];
+          wsn += sc * r;
+          wnn += vbn * r;
+        }
       }
       const float invR = 1.0f / (float)a.R;
+      if (d.nyq) {
+        const float s = sum_c(wsn) * invR, nn = sum_c(wnn) * invR;
+        if (on && w == 0 && q == 0 && dw.F - 1 + c < a.Fs) {       // lane 0: the bin; lanes 1..: zero the padding
+          const size_t o = (size_t)n * a.Fs + dw.F - 1 + c;
+          const float ms = c == 0 ? s : 0.f, mn = c == 0 ? nn : 0.f;
+          const float xr = a.X[2 * o], xi = a.X[2 * o + 1];
+          a.S_hat[2 * o] = ms * xr;  a.S_hat[2 * o + 1] = ms * xi;
+          a.N_hat[2 * o] = mn * xr;  a.N_hat[2 * o + 1] = mn * xi;
+          if (a.WFs) a.WFs[o] = ms;
+          if (a.WFn) a.WFn[o] = mn;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
         const float s = sum_q(ws[i]) * invR, nn = sum_q(wn[i]) * invR;
@@ -812,7 +934,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       // chunk validity mask (chunk 0 uses mk; later chunks are rare: R > 32)
       auto mask = [&](int ch, int sg, int t) { return ch == 0 ? mk[sg][t] : (rvalid(ch, sg, t) ? 1.f : 0.f); };
       // ---- H update (mcem.py:118-121): W already updated + normalised by w_update_kernel
-      float a1[MAXT], a2[MAXT];
+      float a1[MAXT], a2[MAXT], a1n = 0.f, a2n = 0.f;
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) a1[i] = a2[i] = 0.f;
       VN_STAMP_AT(0);
@@ -829,6 +951,12 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
               a1[i] += r;
               a2[i] += r * r;
             }
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+          const float r = fast_rcp(gn * vsn[sg] + vbn) * mkn[sg];
+          a1n += r;
+          a2n += r * r;
+        }
       }
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
@@ -836,6 +964,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
         a1[i] = fval[i] ? s1 : 0.f;
         a2[i] = fval[i] ? s2 * x2f[i] : 0.f;
       }
+      if (d.nyq) { a1n = sum_c(a1n); a2n = sum_c(a2n) * x2n; }
       VN_STAMP_AT(2);
       // num_k = sum_f W[f,k] X2 A2, den_k = sum_f W[f,k] A1: in-lane over this wave's bins, DPP row sum
       // over the 16 bins of a tile, one LDS hop over the waves
@@ -852,6 +981,14 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
             for (int t = 0; t < 4; ++t) { nuk[k + t] += ww[t] * a2[i]; dek[k + t] += ww[t] * a1[i]; }
           }
         }
+      if (d.nyq && lead) {
+#pragma unroll
+        for (int k = 0; k < Kp; k += 4) {
+          const f32x4 ww = wn4(k);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { nuk[k + t] += ww[t] * a2n; dek[k + t] += ww[t] * a1n; }
+        }
+      }
 #pragma unroll
       for (int k = 0; k < Kp; ++k) { nuk[k] = sum_c(nuk[k]); dek[k] = sum_c(dek[k]); }
       if (lane == 0) {
@@ -887,7 +1024,15 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       // ---- variances with the new W, H (mcem.py:124-125), then g update (mcem.py:138-142)
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) vb[i] = (w + NW * i < dw.NT3) ? dotWH(i, hn) : 1.f;
-      float ng[MAXT], dg[MAXT];
+      float ng[MAXT], dg[MAXT], ngn = 0.f, dgn = 0.f, vbn2 = 1.f;
+      if (d.nyq) {
+        vbn2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < Kp; k += 4) {
+          const f32x4 ww = wn4(k);
+          vbn2 += ww[0] * hn[k] + ww[1] * hn[k + 1] + ww[2] * hn[k + 2] + ww[3] * hn[k + 3];
+        }
+      }
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) ng[i] = dg[i] = 0.f;
       for (int ch = 0; ch < nch; ++ch) {
@@ -904,12 +1049,23 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
               dg[i] += vr;            // sum_r Vs / Vx
               ng[i] += vr * r;        // sum_r Vs / Vx^2
             }
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+          const float r = fast_rcp(gn * vsn[sg] + vbn2) * mkn[sg];
+          const float vr = vsn[sg] * r;
+          dgn += vr;
+          ngn += vr * r;
+        }
       }
       float nu = 0.f, de = 0.f;
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
         const float sn = sum_q(ng[i]), sdn = sum_q(dg[i]);
         if (fval[i]) { nu += x2f[i] * sn; de += sdn; }
+      }
+      if (d.nyq) {
+        const float sn = sum_c(ngn), sdn = sum_c(dgn);
+        if (lead) { nu += x2n * sn; de += sdn; }
       }
       nu = sum_c(nu);
       de = sum_c(de);
@@ -923,7 +1079,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       const float gnew = gn * __builtin_amdgcn_sqrtf(nu * fast_rcp(de));          // mcem.py:142
       if (on && w == 0 && lane == 0) a.g[n] = gnew;
       // ---- cost (mcem.py:70) with the refreshed variances (mcem.py:151-152)
-      float cs = 0.f;
+      float cs = 0.f, csn = 0.f;
       for (int ch = 0; ch < nch; ++ch) {
         if (nch > 1) decode_chunk(ch, vs);
 #pragma unroll
@@ -938,6 +1094,15 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
             }
           cs += fval[i] ? ci : 0.f;
         }
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+          const float vx = gnew * vsn[sg] + vbn2;
+          csn += (fast_log(vx) + x2n * fast_rcp(vx)) * mkn[sg];
+        }
+      }
+      if (d.nyq) {
+        const float t = sum_c(csn);
+        if (lead) cs += t;
       }
       // wave sum: rows in fp32 (DPP), then fp64 across the 4 rows and the waves
       double cd = sum_rows4_d((double)sum_c(cs));
@@ -968,7 +1133,7 @@ DecW make_decw(const vaenmf_plan* p) {
   DecW d;
   d.w1f = p->w1f; d.w2f = p->w2f; d.w3f = p->w3f;
   d.b1 = p->b1; d.b2 = p->b2; d.b3 = p->b3;
-  d.NT3 = p->NT3; d.F = p->cfg.F;
+  d.NT3 = p->NT3; d.F = p->cfg.F; d.Fm = p->Fm; d.w3n = p->w3n;
   return d;
 }
 
@@ -1023,18 +1188,19 @@ int launch_decode_kp(DecodeArgs a, int Kp, int grid, hipStream_t st) {
   }
   return 0;
 }
-// workgroup geometry: geom 0 = 2 teams x 4 waves (5 bin tiles per wave, F <= 320),
-//                     geom 1 = 2 teams x 8 waves (3 bin tiles per wave, F <= 384),
-//                     geom 2 = 1 team  x 8 waves (5 bin tiles per wave, F <= 640)
+// workgroup geometry (plan.hip picks it from the number of bin tiles NT3 of the MFMA path):
+//   0 = 2 teams x 4 waves, 5 bin tiles per wave (NT3 <= 20)      3 = 2 teams x 4 waves, 4 tiles (NT3 <= 16)
+//   2 = 1 team  x 8 waves, 5 bin tiles per wave (NT3 <= 40)      4 = 1 team  x 8 waves, 4 tiles (NT3 <= 32)
 template <int MODE>
 int launch_decode(const vaenmf_plan* p, const DecodeArgs& a, hipStream_t st) {
   const int want = p->n_sms * 2;
   const int grid = a.NT < want ? a.NT : want;
   const bool split = p->cfg.precision == VAENMF_PREC_BF16X3;
   const int Kp = (MODE == MODE_STORE) ? 8 : p->Kp;
-  switch (p->geom_dec) {
+  switch (p->geom) {
     case 0: return split ? launch_decode_kp<4, 2, 5, true, MODE>(a, Kp, grid, st) : launch_decode_kp<4, 2, 5, false, MODE>(a, Kp, grid, st);
-    case 1: return split ? launch_decode_kp<8, 2, 3, true, MODE>(a, Kp, grid, st) : launch_decode_kp<8, 2, 3, false, MODE>(a, Kp, grid, st);
+    case 3: return split ? launch_decode_kp<4, 2, 4, true, MODE>(a, Kp, grid, st) : launch_decode_kp<4, 2, 4, false, MODE>(a, Kp, grid, st);
+    case 4: return split ? launch_decode_kp<8, 1, 4, true, MODE>(a, Kp, grid, st) : launch_decode_kp<8, 1, 4, false, MODE>(a, Kp, grid, st);
     default: return split ? launch_decode_kp<8, 1, 5, true, MODE>(a, Kp, grid, st) : launch_decode_kp<8, 1, 5, false, MODE>(a, Kp, grid, st);
   }
 }
@@ -1079,7 +1245,8 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
   ProfScope ps(p, VN_K_CHAIN, st);
   switch (p->geom) {
     case 0: if (split) launch_chain<4, 2, 5, true>(a, p->n_tiles, st); else launch_chain<4, 2, 5, false>(a, p->n_tiles, st); break;
-    case 1: if (split) launch_chain<8, 2, 3, true>(a, p->n_tiles, st); else launch_chain<8, 2, 3, false>(a, p->n_tiles, st); break;
+    case 3: if (split) launch_chain<4, 2, 4, true>(a, p->n_tiles, st); else launch_chain<4, 2, 4, false>(a, p->n_tiles, st); break;
+    case 4: if (split) launch_chain<8, 1, 4, true>(a, p->n_tiles, st); else launch_chain<8, 1, 4, false>(a, p->n_tiles, st); break;
     default: if (split) launch_chain<8, 1, 5, true>(a, p->n_tiles, st); else launch_chain<8, 1, 5, false>(a, p->n_tiles, st); break;
   }
   VN_CHECK_HIP(hipGetLastError());

@@ -79,23 +79,19 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   memset((void*)&p->cfg, 0, sizeof(p->cfg));
   p->cfg = *cfg;
   p->Fs = (cfg->F + 15) / 16 * 16;
-  p->NT3 = p->Fs / 16;
+  p->Fm = (cfg->F % 16 == 1 && cfg->F > 16) ? cfg->F - 1 : cfg->F;    // n_fft/2+1 bins: the last one leaves the tiles
+  p->NT3 = (p->Fm + 15) / 16;
   p->Kp = cfg->K <= 8 ? 8 : (cfg->K <= 16 ? 16 : 32);
   {
-    const char* g = getenv("VAENMF_GEOM");          // dev override (A/B runs)
-    // 2x4 waves (256 registers per wave: the X2/Vb tiles of the chain stay in registers) when F <= 320
-    int geom = p->NT3 <= 20 ? 0 : 2;
-    if (g && g[0] == '1' && p->NT3 <= 24) geom = 1;
-    if (g && g[0] == '2') geom = 2;
+    const char* g = getenv("VAENMF_GEOM");          // dev override (A/B runs): force one team of 8 waves
+    int geom = p->NT3 <= 16 ? 3 : (p->NT3 <= 20 ? 0 : (p->NT3 <= 32 ? 4 : 2));
+    if (g && g[0] == '2') geom = p->NT3 <= 32 ? 4 : 2;
     p->geom = geom;
-    p->geom_dec = p->NT3 <= 20 ? 0 : (p->NT3 <= 24 ? 1 : 2);
-    if (g && g[0] && g[1] == '1' && p->NT3 <= 24) p->geom_dec = 1;
-    if (g && g[0] && g[1] == '2') p->geom_dec = 2;
-    p->nwaves = geom == 0 ? 4 : 8;
-    p->tile_frames = geom == 2 ? 32 : 64;
+    p->nwaves = (geom == 0 || geom == 3) ? 4 : 8;
+    p->tile_frames = (geom == 0 || geom == 3) ? 64 : 32;
   }
   p->w1f = p->w2f = p->w3f = nullptr;
-  p->b1 = p->b2 = p->b3 = p->w1y = nullptr;
+  p->b1 = p->b2 = p->b3 = p->w1y = p->w3n = nullptr;
   p->Dy = 0;
   p->have_weights = false;
   p->n_utt = p->NT = p->n_tiles = 0;
@@ -115,6 +111,7 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   e |= dev_alloc(&p->b1, HID);
   e |= dev_alloc(&p->b2, HID);
   e |= dev_alloc(&p->b3, p->Fs);
+  e |= dev_alloc(&p->w3n, HID);
   e |= dev_alloc(&p->d_frame_off, Uc + 1);
   e |= dev_alloc(&p->d_tile_utt, max_tiles);
   e |= dev_alloc(&p->d_tile_n0, max_tiles);
@@ -134,7 +131,7 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
 
 extern "C" void vaenmf_plan_destroy(vaenmf_plan* p) {
   if (!p) return;
-  void* ptrs[] = {p->w1f, p->w2f, p->w3f, p->b1, p->b2, p->b3, p->w1y, p->d_frame_off, p->d_tile_utt, p->d_tile_n0,
+  void* ptrs[] = {p->w1f, p->w2f, p->w3f, p->b1, p->b2, p->b3, p->w3n, p->w1y, p->d_frame_off, p->d_tile_utt, p->d_tile_n0,
                   p->d_tile_cnt, p->d_frame_utt, p->d_frame_loc, p->d_utt_seed, p->A1, p->P, p->normW, p->wpart, p->cost_frames};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -161,7 +158,7 @@ extern "C" int vaenmf_set_decoder_weights(vaenmf_plan* p, const float* W1, int32
   const int F = p->cfg.F;
   std::vector<uint16_t> f1 = pack_weights(W1, HID, LAT, in1, HID / 16, 1);
   std::vector<uint16_t> f2 = pack_weights(W2, HID, HID, HID, HID / 16, HID / 32);
-  std::vector<uint16_t> f3 = pack_weights(W3, F, HID, HID, p->NT3, HID / 32);
+  std::vector<uint16_t> f3 = pack_weights(W3, p->Fm, HID, HID, p->NT3, HID / 32);
   std::vector<float> b3p(p->Fs, -100.f);      // padding bins: W3 rows are 0, so Vs = exp(-100) ~ 0
   memcpy(b3p.data(), b3, sizeof(float) * F);
   int e = 0;
@@ -171,6 +168,7 @@ extern "C" int vaenmf_set_decoder_weights(vaenmf_plan* p, const float* W1, int32
   e |= upload(p->b1, b1, HID);
   e |= upload(p->b2, b2, HID);
   e |= upload(p->b3, b3p.data(), b3p.size());
+  e |= upload(p->w3n, W3 + (size_t)(F - 1) * HID, HID);
   if (p->w1y) { (void)hipFree(p->w1y); p->w1y = nullptr; }
   p->Dy = in1 - LAT;
   if (p->Dy > 0) {                             // label columns of W1, [H1][Dy]
