@@ -666,7 +666,9 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       }
     }
   };
-  constexpr bool PREFETCH = !SPLIT;               // bf16x3 has no registers to spare for a second frame
+  // Loading the next frame's inputs one iteration ahead was tried: the second register set pushed the
+  // kernels over 256 VGPRs (spills) and lost more than the hidden latency won (HG 0.79 -> 0.67 ms without).
+  constexpr bool PREFETCH = false;
   f32x4 bias1_m1[TPW];                             // M1: the layer-1 bias is the same for every frame
 #pragma unroll
   for (int ti = 0; ti < TPW; ++ti) bias1_m1[ti] = *reinterpret_cast<const f32x4*>(dw.b1 + 16 * (w + NW * ti) + 4 * q);
