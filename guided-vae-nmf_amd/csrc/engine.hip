@@ -970,34 +970,38 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       VN_STAMP_AT(2);
       // num_k = sum_f W[f,k] X2 A2, den_k = sum_f W[f,k] A1: in-lane over this wave's bins, DPP row sum
       // over the 16 bins of a tile, one LDS hop over the waves
-      float nuk[KP], dek[KP];
+      // (ranks in groups of 8 so that a large rank does not need 2*KP live accumulators)
 #pragma unroll
-      for (int k = 0; k < Kp; ++k) nuk[k] = dek[k] = 0.f;
+      for (int k0 = 0; k0 < Kp; k0 += 8) {
+        float nuk[8], dek[8];
 #pragma unroll
-      for (int i = 0; i < MAXT; ++i)
-        if (w + NW * i < dw.NT3) {
+        for (int k = 0; k < 8; ++k) nuk[k] = dek[k] = 0.f;
 #pragma unroll
-          for (int k = 0; k < Kp; k += 4) {
-            const f32x4 ww = wrow(i, k);
+        for (int i = 0; i < MAXT; ++i)
+          if (w + NW * i < dw.NT3) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { nuk[k + t] += ww[t] * a2[i]; dek[k + t] += ww[t] * a1[i]; }
+            for (int k = 0; k < 8; k += 4) {
+              const f32x4 ww = wrow(i, k0 + k);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) { nuk[k + t] += ww[t] * a2[i]; dek[k + t] += ww[t] * a1[i]; }
+            }
+          }
+        if (d.nyq && lead) {
+#pragma unroll
+          for (int k = 0; k < 8; k += 4) {
+            const f32x4 ww = wn4(k0 + k);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { nuk[k + t] += ww[t] * a2n; dek[k + t] += ww[t] * a1n; }
           }
         }
-      if (d.nyq && lead) {
 #pragma unroll
-        for (int k = 0; k < Kp; k += 4) {
-          const f32x4 ww = wn4(k);
+        for (int k = 0; k < 8; ++k) { nuk[k] = sum_c(nuk[k]); dek[k] = sum_c(dek[k]); }
+        if (lane == 0) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) { nuk[k + t] += ww[t] * a2n; dek[k + t] += ww[t] * a1n; }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < Kp; ++k) { nuk[k] = sum_c(nuk[k]); dek[k] = sum_c(dek[k]); }
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < Kp; k += 4) {
-          *reinterpret_cast<f32x4*>(&L.redH[w][k]) = f32x4{nuk[k], nuk[k + 1], nuk[k + 2], nuk[k + 3]};
-          *reinterpret_cast<f32x4*>(&L.redH[w][32 + k]) = f32x4{dek[k], dek[k + 1], dek[k + 2], dek[k + 3]};
+          for (int k = 0; k < 8; k += 4) {
+            *reinterpret_cast<f32x4*>(&L.redH[w][k0 + k]) = f32x4{nuk[k], nuk[k + 1], nuk[k + 2], nuk[k + 3]};
+            *reinterpret_cast<f32x4*>(&L.redH[w][32 + k0 + k]) = f32x4{dek[k], dek[k + 1], dek[k + 2], dek[k + 3]};
+          }
         }
       }
       VN_STAMP_AT(3);
