@@ -187,7 +187,7 @@ def main():
         flops_chain_avg = flop_row * (rows_e * n_e + rows_w * n_w) / max(n_e + n_w, 1)
         achieved = flops_chain_avg / (chain_ms * 1e-3) / 1e12 if chain_ms > 0 else 0.0
         # HBM bytes of the chain kernel per launch from the committed rocprofv3 PMC passes of this command
-        # (profiles/round1_<precision>_traffic.json; collected with scripts_dev/profile.sh), else null
+        # (profiles/round1_<precision>_traffic.json; collected with tools/profile.sh), else null
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "round1_%s_traffic.json" % args.precision)))

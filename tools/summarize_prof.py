@@ -1,4 +1,4 @@
-"""dev aid: condense the rocprofv3 outputs of scripts_dev/profile.sh into profiles/<tag>_summary.txt"""
+"""dev aid: condense the rocprofv3 outputs of tools/profile.sh into profiles/<tag>_summary.txt"""
 import csv, glob, collections, sys, os, json
 tag = sys.argv[1]; src = sys.argv[2]; out = sys.argv[3]
 lines = []
