@@ -122,6 +122,10 @@ struct Dec {
   // decoupling the teams did not pay -- mh_chain 0.62 -> 0.68 ms per launch -- so it was dropped.)
   __device__ __forceinline__ void team_sync() const { __syncthreads(); }
 
+  // MT == 4 instantiations are only launched when every wave owns exactly 4 bin tiles (NT3 == 4 NW:
+  // F = 257 with 4 waves, F = 513 with 8), so their tile loops carry no validity checks
+  __device__ __forceinline__ bool tile_ok(int i) const { return MT == 4 || w + NW * i < NT3; }
+
   static __device__ __forceinline__ int act_off(int cg, int s) { return (cg * NK_H + s) * M::PARTS * 1024; }
 
   __device__ __forceinline__ void lds_w(int base, int tile, int nk, int s, bf16x8& hi, bf16x8& lo) const {
@@ -239,7 +243,7 @@ struct Dec {
       act_frag(act2, 1, s, ahi[1], alo[1]);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        if (w + NW * i < NT3) {   // wave-uniform (w is an SGPR value)
+        if (tile_ok(i)) {   // wave-uniform (w is an SGPR value)
           bf16x8 whi, wlo;
           w3_frag(i, s, whi, wlo);
 #pragma unroll
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
   for (int i = 0; i < MAXT; ++i) {
     const int t16 = w + NW * i;
     const int f0 = 16 * t16 + 4 * q;
-    const bool tv = t16 < dw.NT3;
+    const bool tv = d.tile_ok(i);
 #pragma unroll
     for (int fg = 0; fg < 2; ++fg) {
       f32x4 xv = tv ? *reinterpret_cast<const f32x4*>(a.X2 + (size_t)nrow[fg] * a.Fs + f0) : f32x4{0, 0, 0, 0};
@@ -449,14 +453,14 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
     f32x4 acc[MAXT][2];
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
-      const f32x4 bv = (w + NW * i < dw.NT3) ? *reinterpret_cast<const f32x4*>(b3l + 16 * (w + NW * i) + 4 * q) : f32x4{0, 0, 0, 0};
+      const f32x4 bv = (d.tile_ok(i)) ? *reinterpret_cast<const f32x4*>(b3l + 16 * (w + NW * i) + 4 * q) : f32x4{0, 0, 0, 0};
       acc[i][0] = bv; acc[i][1] = bv;
     }
     d.template out_layer<false>(acc);
     double e[2] = {0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
-      if (w + NW * i < dw.NT3) {
+      if (d.tile_ok(i)) {
 #pragma unroll
         for (int fg = 0; fg < 2; ++fg) {
           float part = 0.f;
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
   for (int i = 0; i < MAXT; ++i) {
     const int t16 = w + NW * i;
     fidx[i] = 16 * t16 + c;
-    fval[i] = t16 < dw.NT3 && fidx[i] < dw.Fm;
+    fval[i] = d.tile_ok(i) && fidx[i] < dw.Fm;
   }
   // contiguous chunk of frames per workgroup; the teams take alternate frames of the chunk
   const int per = (a.NT + gridDim.x - 1) / gridDim.x;
@@ -657,7 +661,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       f.g = a.g[n];
       f.x2n = d.nyq ? a.X2[(size_t)n * a.Fs + dw.F - 1] : 0.f;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) f.x2f[i] = (w + NW * i < dw.NT3) ? a.X2[(size_t)n * a.Fs + fidx[i]] : 0.f;
+      for (int i = 0; i < MT; ++i) f.x2f[i] = (d.tile_ok(i)) ? a.X2[(size_t)n * a.Fs + fidx[i]] : 0.f;
 #pragma unroll
       for (int k = 0; k < KP; k += 4) {
         const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
@@ -725,7 +729,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       d.hidden(zhi, zlo, bias1, []() {});
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
-        const float bv = (w + NW * i < dw.NT3) ? b3l[fidx[i]] : 0.f;
+        const float bv = (d.tile_ok(i)) ? b3l[fidx[i]] : 0.f;
         vs[i][0] = f32x4{bv, bv, bv, bv};
         vs[i][1] = vs[i][0];
       }
@@ -762,7 +766,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
         if (on) {
 #pragma unroll
           for (int i = 0; i < MAXT; ++i)
-            if (w + NW * i < dw.NT3)
+            if (d.tile_ok(i))
 #pragma unroll
               for (int sg = 0; sg < 2; ++sg)
 #pragma unroll
@@ -791,7 +795,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int k = 0; k < Kp; k += 4) {
-          const f32x4 ww = (w + NW * i < dw.NT3) ? *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + fidx[i]) * Kp + k)
+          const f32x4 ww = (d.tile_ok(i)) ? *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + fidx[i]) * Kp + k)
                                                  : f32x4{0, 0, 0, 0};
 #pragma unroll
           for (int t = 0; t < 4; ++t) wreg[WCACHE ? i : 0][k + t] = ww[t];
@@ -820,7 +824,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
     }
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
-      const bool tv = w + NW * i < dw.NT3;
+      const bool tv = d.tile_ok(i);
       x2f[i] = cur.x2f[i];
       vb[i] = tv ? dotWH(i, hs) : 1.f;
     }
@@ -866,7 +870,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
         const float s1 = sum_q(a1[i]), s2 = sum_q(a2[i]);
-        if (on && q == 0 && w + NW * i < dw.NT3) {
+        if (on && q == 0 && d.tile_ok(i)) {
           a.A1[(size_t)n * a.Fs + fidx[i]] = fval[i] ? s1 : 0.f;
           a.P[(size_t)n * a.Fs + fidx[i]] = fval[i] ? x2f[i] * s2 : 0.f;
         }
@@ -922,7 +926,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
         const float s = sum_q(ws[i]) * invR, nn = sum_q(wn[i]) * invR;
-        if (on && q == 0 && w + NW * i < dw.NT3) {
+        if (on && q == 0 && d.tile_ok(i)) {
           const size_t o = (size_t)n * a.Fs + fidx[i];
           const float xr = a.X[2 * o], xi = a.X[2 * o + 1];
           a.S_hat[2 * o] = fval[i] ? s * xr : 0.f;  a.S_hat[2 * o + 1] = fval[i] ? s * xi : 0.f;   // mcem.py:175
@@ -978,7 +982,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
         for (int k = 0; k < 8; ++k) nuk[k] = dek[k] = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXT; ++i)
-          if (w + NW * i < dw.NT3) {
+          if (d.tile_ok(i)) {
 #pragma unroll
             for (int k = 0; k < 8; k += 4) {
               const f32x4 ww = wrow(i, k0 + k);
@@ -1029,7 +1033,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       VN_STAMP_AT(5);
       // ---- variances with the new W, H (mcem.py:124-125), then g update (mcem.py:138-142)
 #pragma unroll
-      for (int i = 0; i < MAXT; ++i) vb[i] = (w + NW * i < dw.NT3) ? dotWH(i, hn) : 1.f;
+      for (int i = 0; i < MAXT; ++i) vb[i] = (d.tile_ok(i)) ? dotWH(i, hn) : 1.f;
       float ng[MAXT], dg[MAXT], ngn = 0.f, dgn = 0.f, vbn2 = 1.f;
       if (d.nyq) {
         vbn2 = 0.f;

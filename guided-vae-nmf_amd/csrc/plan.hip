@@ -84,8 +84,9 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   p->Kp = cfg->K <= 8 ? 8 : (cfg->K <= 16 ? 16 : 32);
   {
     const char* g = getenv("VAENMF_GEOM");          // dev override (A/B runs): force one team of 8 waves
-    int geom = p->NT3 <= 16 ? 3 : (p->NT3 <= 20 ? 0 : (p->NT3 <= 32 ? 4 : 2));
-    if (g && g[0] == '2') geom = p->NT3 <= 32 ? 4 : 2;
+    // geometries 3 / 4 (4 bin tiles per wave, no tile checks) need exactly 16 / 32 tiles: F = 257 / 513
+    int geom = p->NT3 == 16 ? 3 : (p->NT3 <= 20 ? 0 : (p->NT3 == 32 ? 4 : 2));
+    if (g && g[0] == '2') geom = p->NT3 == 32 ? 4 : 2;
     p->geom = geom;
     p->nwaves = (geom == 0 || geom == 3) ? 4 : 8;
     p->tile_frames = (geom == 0 || geom == 3) ? 64 : 32;
