@@ -81,13 +81,18 @@ struct ProfScope {   // records a (start, stop) event pair around a launch when 
 
 // ---- device helpers --------------------------------------------------------
 #if defined(__HIPCC__)
-__device__ __forceinline__ float fast_tanh(float x) {
-  // tanh(x) = 1 - 2/(exp(2x)+1); exp via v_exp_f32 (2^x).  abs error ~2e-7.
-  float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+// The decoder weights are pre-scaled on the host (plan.hip): hidden layers by 2 log2(e), the output layer by
+// log2(e), so the MFMA accumulators are already the arguments of v_exp_f32 (2^x):
+//   tanh(x) = 1 - 2/(exp(2x)+1) = 1 - 2/(2^(xs)+1),  xs = 2 log2(e) x      (abs error ~2e-7)
+//   exp(a)  = 2^(as),                                 as = log2(e) a
+__device__ __forceinline__ float fast_tanh(float xs) {
+  float e = __builtin_amdgcn_exp2f(xs);
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_exp(float as) { return __builtin_amdgcn_exp2f(as); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+constexpr float LN2_F = 0.6931471805599453f;
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // split 4 floats into bf16 hi and lo parts: v ~= hi + lo (error ~2^-17 |v|)

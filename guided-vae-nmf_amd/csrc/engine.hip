@@ -488,14 +488,15 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
 #pragma unroll
           for (int fg = 0; fg < 2; ++fg) {
             const f32x4 acc = fg == 0 ? acc0 : acc1;
-            float part = 0.f;
+            float pl = 0.f, px = 0.f;                       // sum log2 Vx, sum X2 / Vx
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
               const float vs = fast_exp(acc[t]);
               const float vx = gn[fg] * vs + vb[i][fg][t];
-              part += fast_log(vx) + x2[i][fg][t] * fast_rcp(vx);
+              pl += fast_log2(vx);
+              px += x2[i][fg][t] * fast_rcp(vx);
             }
-            e[fg] += (double)part;
+            e[fg] += (double)(pl * LN2_F + px);
           }
         });
     if (d.nyq) {
@@ -1128,15 +1129,17 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
         if (nch > 1) decode_chunk(ch, vs);
 #pragma unroll
         for (int i = 0; i < MAXT; ++i) {
-          float ci = 0.f;
+          float cl = 0.f, cx = 0.f;                         // sum log2 Vx, sum 1/Vx over this lane's samples
 #pragma unroll
           for (int sg = 0; sg < 2; ++sg)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
               const float vx = gnew * vs[i][sg][t] + vb[i];
-              ci += (fast_log(vx) + x2f[i] * fast_rcp(vx)) * mask(ch, sg, t);
+              const float m = mask(ch, sg, t);
+              cl += fast_log2(vx) * m;
+              cx += fast_rcp(vx) * m;
             }
-          cs += fval[i] ? ci : 0.f;
+          cs += fval[i] ? cl * LN2_F + x2f[i] * cx : 0.f;
         }
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {

@@ -157,24 +157,34 @@ extern "C" int vaenmf_set_decoder_weights(vaenmf_plan* p, const float* W1, int32
   VN_REQUIRE(p && W1 && b1 && W2 && b2 && W3 && b3, "null argument");
   VN_REQUIRE(in1 >= LAT, "decoder input width %d < latent dim %d", in1, LAT);
   const int F = p->cfg.F;
-  std::vector<uint16_t> f1 = pack_weights(W1, HID, LAT, in1, HID / 16, 1);
-  std::vector<uint16_t> f2 = pack_weights(W2, HID, HID, HID, HID / 16, HID / 32);
-  std::vector<uint16_t> f3 = pack_weights(W3, p->Fm, HID, HID, p->NT3, HID / 32);
-  std::vector<float> b3p(p->Fs, -100.f);      // padding bins: W3 rows are 0, so Vs = exp(-100) ~ 0
-  memcpy(b3p.data(), b3, sizeof(float) * F);
+  // pre-scale so that the accumulators are v_exp_f32 arguments (common.h: fast_tanh / fast_exp)
+  const double C2 = 2.0 * 1.4426950408889634, C1 = 1.4426950408889634;
+  auto scaled = [](const float* src, size_t n, double c) {
+    std::vector<float> v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = (float)((double)src[i] * c);
+    return v;
+  };
+  const std::vector<float> W1s = scaled(W1, (size_t)HID * in1, C2), b1s = scaled(b1, HID, C2);
+  const std::vector<float> W2s = scaled(W2, (size_t)HID * HID, C2), b2s = scaled(b2, HID, C2);
+  const std::vector<float> W3s = scaled(W3, (size_t)F * HID, C1), b3s = scaled(b3, F, C1);
+  std::vector<uint16_t> f1 = pack_weights(W1s.data(), HID, LAT, in1, HID / 16, 1);
+  std::vector<uint16_t> f2 = pack_weights(W2s.data(), HID, HID, HID, HID / 16, HID / 32);
+  std::vector<uint16_t> f3 = pack_weights(W3s.data(), p->Fm, HID, HID, p->NT3, HID / 32);
+  std::vector<float> b3p(p->Fs, -100.f);      // padding bins: W3 rows are 0, so Vs = 2^-100 ~ 0
+  memcpy(b3p.data(), b3s.data(), sizeof(float) * F);
   int e = 0;
   e |= upload((uint16_t*)p->w1f, f1.data(), f1.size());
   e |= upload((uint16_t*)p->w2f, f2.data(), f2.size());
   e |= upload((uint16_t*)p->w3f, f3.data(), f3.size());
-  e |= upload(p->b1, b1, HID);
-  e |= upload(p->b2, b2, HID);
+  e |= upload(p->b1, b1s.data(), HID);
+  e |= upload(p->b2, b2s.data(), HID);
   e |= upload(p->b3, b3p.data(), b3p.size());
-  e |= upload(p->w3n, W3 + (size_t)(F - 1) * HID, HID);
+  e |= upload(p->w3n, W3s.data() + (size_t)(F - 1) * HID, HID);
   if (p->w1y) { (void)hipFree(p->w1y); p->w1y = nullptr; }
   p->Dy = in1 - LAT;
-  if (p->Dy > 0) {                             // label columns of W1, [H1][Dy]
+  if (p->Dy > 0) {                             // label columns of W1 (scaled like the rest of layer 1), [H1][Dy]
     std::vector<float> wy((size_t)HID * p->Dy);
-    for (int h = 0; h < HID; ++h) memcpy(&wy[(size_t)h * p->Dy], W1 + (size_t)h * in1 + LAT, sizeof(float) * p->Dy);
+    for (int h = 0; h < HID; ++h) memcpy(&wy[(size_t)h * p->Dy], W1s.data() + (size_t)h * in1 + LAT, sizeof(float) * p->Dy);
     e |= dev_alloc(&p->w1y, wy.size());
     if (!e) e |= upload(p->w1y, wy.data(), wy.size());
   }
