@@ -169,3 +169,27 @@ def test_dropin_import_paths():
             if k == "python" or k.startswith("python."):
                 del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_wav_io_and_speech_list(tmp_path):
+    """sf.read/sf.write semantics on RIFF PCM-16 (evaluate_M1.py:114,165) and the sorted recursive file list
+    (python/dataset/csr1_wjs0_dataset.py:19-54)."""
+    from vaenmf import wavio
+    from vaenmf.driver import speech_list
+    z = np.load(GOLDEN + "/metrics_dummy_m2.npz")
+    pcm = z["a_s"][:5000]
+    root = str(tmp_path) + "/"
+    d = root + "CSR-1-WSJ-0/WAV/wsj0/si_et_05/440/"
+    os.makedirs(d)
+    os.makedirs(root + "CSR-1-WSJ-0/WAV/wsj0/si_tr_s/011/")
+    for name in ("440c020b", "440c020a"):
+        wavio.write(d + name + ".wav", pcm / 32768.0, 16000)
+    wavio.write(root + "CSR-1-WSJ-0/WAV/wsj0/si_tr_s/011/011a010a.wav", pcm / 32768.0, 16000)
+    x, fs = wavio.read(d + "440c020a.wav")
+    assert fs == 16000 and x.dtype == np.float64 and len(x) == len(pcm)
+    assert np.max(np.abs(x * 32768.0 - pcm)) <= 1.0          # one LSB: write scales by 32767, read by 1/32768
+    assert speech_list(root, "test") == ["CSR-1-WSJ-0/WAV/wsj0/si_et_05/440/440c020a.wav",
+                                         "CSR-1-WSJ-0/WAV/wsj0/si_et_05/440/440c020b.wav"]
+    assert speech_list(root, "train") == ["CSR-1-WSJ-0/WAV/wsj0/si_tr_s/011/011a010a.wav"]
+    wavio.write(root + "clip.wav", np.array([2.0, -2.0, 0.5]), 16000)
+    assert list((wavio.read(root + "clip.wav")[0] * 32768).astype(int)) == [32767, -32768, 16384]
