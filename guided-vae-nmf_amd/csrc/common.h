@@ -46,6 +46,7 @@ struct vaenmf_plan {
   float* w1y;                // [H1][Dy] label columns of W1 (M2)
   int Dy;
   bool have_weights;
+  const float* Vb_ext;       // caller-owned noise variance [NT][Fs] (noNMF variants) or null
   // bound batch
   int n_utt, NT, n_tiles;
   int32_t *d_frame_off;      // [n_utt+1]

@@ -339,6 +339,7 @@ __device__ long long g_stamp_store[64];
 struct ChainArgs {
   DecW dw;
   const float *X2, *W, *Ht, *g, *B1;
+  const float* Vb;           // external noise variance [NT][Fs] (the *_noNMF variants, mcem.py:493-760) or null: Vb = W H
   float *Z, *Zs, *acc_out;
   const int32_t *tile_utt, *tile_n0, *tile_cnt, *frame_off;
   const uint64_t* utt_seed;
@@ -398,7 +399,9 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
     for (int fg = 0; fg < 2; ++fg) {
       f32x4 xv = tv ? *reinterpret_cast<const f32x4*>(a.X2 + (size_t)nrow[fg] * a.Fs + f0) : f32x4{0, 0, 0, 0};
       f32x4 v = {0, 0, 0, 0};
-      if (tv) {
+      if (tv && a.Vb) {
+        v = *reinterpret_cast<const f32x4*>(a.Vb + (size_t)nrow[fg] * a.Fs + f0);
+      } else if (tv) {
         for (int k = 0; k < a.Kp; k += 4) {
           const f32x4 h = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)nrow[fg] * a.Kp + k);
 #pragma unroll
@@ -422,7 +425,9 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
     for (int fg = 0; fg < 2; ++fg) {
       x2n[fg] = a.X2[(size_t)nrow[fg] * a.Fs + dw.F - 1];
       float v = 0.f;
-      for (int k = 0; k < a.Kp; ++k) v += a.W[((size_t)utt * a.Fs + dw.F - 1) * a.Kp + k] * a.Ht[(size_t)nrow[fg] * a.Kp + k];
+      if (a.Vb) v = a.Vb[(size_t)nrow[fg] * a.Fs + dw.F - 1];
+      else
+        for (int k = 0; k < a.Kp; ++k) v += a.W[((size_t)utt * a.Fs + dw.F - 1) * a.Kp + k] * a.Ht[(size_t)nrow[fg] * a.Kp + k];
       vbn[fg] = v;
     }
   }
@@ -607,11 +612,13 @@ __global__ void rng_fill_kernel(const int32_t* tile_utt, const int32_t* tile_n0,
 // Sample decode + fused epilogues (compute_Vs mcem.py:444-454, M_step :90-152,
 // cost :68-70, compute_WF :486-488)
 // ============================================================================
-enum { MODE_STORE = 0, MODE_WSTATS = 1, MODE_HG = 2, MODE_WF = 3 };
+enum { MODE_STORE = 0, MODE_WSTATS = 1, MODE_HG = 2, MODE_WF = 3,
+       MODE_G = 4 };   // gain update + cost only: the M-step of the *_noNMF variants (mcem.py:543-578)
 
 struct DecodeArgs {
   DecW dw;
   const float *X2, *W, *B1, *Zs, *normW, *X;
+  const float* Vb;                     // external noise variance [NT][Fs] (noNMF variants) or null
   float *Ht, *g;                       // read (and written by MODE_HG)
   float *Vs_out, *A1, *P, *S_hat, *N_hat, *WFs, *WFn;
   double* cost_frames;
@@ -708,13 +715,13 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
   }
   // rows of W of this lane's bins, cached per utterance when the rank is small (K <= 8)
   // register budget: bf16x3 streams W3 hi+lo through registers and MODE_HG keeps all sample variances: no room
-  constexpr bool WCACHE = (KP == 8) && !SPLIT && MODE != MODE_HG;
+  constexpr bool WCACHE = (KP == 8) && !SPLIT && MODE != MODE_HG && MODE != MODE_G;
   float wreg[WCACHE ? MT : 1][KP];
   int wutt = -1;
 
   int pend_n = -1, pend_par = 0, cpar = 0;        // MODE_HG: frame whose cost partials wait in LDS
   auto finish_cost = [&]() {
-    if (MODE == MODE_HG && pend_n >= 0 && w == 0 && lane == 0) {
+    if ((MODE == MODE_HG || MODE == MODE_G) && pend_n >= 0 && w == 0 && lane == 0) {
       double s = 0.0;
       for (int ww = 0; ww < NW; ++ww) s += L.redC[pend_par][ww];
       a.cost_frames[pend_n] = s;
@@ -853,7 +860,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
 #pragma unroll
     for (int k = 0; k < Kp; k += 4) {
       f32x4 nv = {1.f, 1.f, 1.f, 1.f};
-      if (MODE == MODE_HG) nv = *reinterpret_cast<const f32x4*>(a.normW + (size_t)utt * Kp + k);
+      if (MODE == MODE_HG) nv = *reinterpret_cast<const f32x4*>(a.normW + (size_t)utt * Kp + k);   // (MODE_G: H is not used)
 #pragma unroll
       for (int t = 0; t < 4; ++t) hs[k + t] = cur.hrow[k + t] * nv[t];
     }
@@ -861,14 +868,16 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
     for (int i = 0; i < MAXT; ++i) {
       const bool tv = d.tile_ok(i);
       x2f[i] = cur.x2f[i];
-      vb[i] = tv ? dotWH(i, hs) : 1.f;
+      vb[i] = !tv ? 1.f : (a.Vb ? a.Vb[(size_t)n * a.Fs + fidx[i]] : dotWH(i, hs));
     }
 
     // W[utt][F-1][:] (odd last bin), re-read at its three uses (same address in every lane: one L1 line)
     auto wn4 = [&](int k) { return *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + dw.F - 1) * Kp + k); };
     float vbn = 1.f;
     const float x2n = cur.x2n;
-    if (d.nyq) {
+    if (d.nyq && a.Vb) {
+      vbn = a.Vb[(size_t)n * a.Fs + dw.F - 1];
+    } else if (d.nyq) {
       vbn = 0.f;
 #pragma unroll
       for (int k = 0; k < Kp; k += 4) {
@@ -969,10 +978,14 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
           if (a.WFn) a.WFn[o] = fval[i] ? nn : 0.f;
         }
       }
-    } else if (MODE == MODE_HG) {
+    } else if (MODE == MODE_HG || MODE == MODE_G) {
       f32x4 vs[MAXT][2];
       // chunk validity mask (chunk 0 uses mk; later chunks are rare: R > 32)
       auto mask = [&](int ch, int sg, int t) { return ch == 0 ? mk[sg][t] : (rvalid(ch, sg, t) ? 1.f : 0.f); };
+      float vbn2 = vbn;
+      if (MODE == MODE_G) {
+        if (nch == 1) decode_chunk(0, vs);
+      } else {
       // ---- H update (mcem.py:118-121): W already updated + normalised by w_update_kernel
       float a1[MAXT], a2[MAXT], a1n = 0.f, a2n = 0.f;
 #pragma unroll
@@ -1066,10 +1079,9 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
           *reinterpret_cast<f32x4*>(a.Ht + (size_t)n * Kp + k) = f32x4{hn[k], hn[k + 1], hn[k + 2], hn[k + 3]};
       }
       VN_STAMP_AT(5);
-      // ---- variances with the new W, H (mcem.py:124-125), then g update (mcem.py:138-142)
+      // ---- variances with the new W, H (mcem.py:124-125)
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) vb[i] = (d.tile_ok(i)) ? dotWH(i, hn) : 1.f;
-      float ng[MAXT], dg[MAXT], ngn = 0.f, dgn = 0.f, vbn2 = 1.f;
       if (d.nyq) {
         vbn2 = 0.f;
 #pragma unroll
@@ -1078,6 +1090,9 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
           vbn2 += ww[0] * hn[k] + ww[1] * hn[k + 1] + ww[2] * hn[k + 2] + ww[3] * hn[k + 3];
         }
       }
+      }   // MODE_HG
+      // ---- g update (mcem.py:138-142 / :564-568)
+      float ng[MAXT], dg[MAXT], ngn = 0.f, dgn = 0.f;
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) ng[i] = dg[i] = 0.f;
       for (int ch = 0; ch < nch; ++ch) {
@@ -1118,6 +1133,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       if (lane == 0) { L.redG[w][0] = nu; L.redG[w][1] = de; }
       d.team_sync();
       VN_STAMP_AT(7);
+      if (MODE == MODE_G) finish_cost();
       nu = de = 0.f;
 #pragma unroll
       for (int ww = 0; ww < NW; ++ww) { nu += L.redG[ww][0]; de += L.redG[ww][1]; }
@@ -1163,7 +1179,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       VN_STAMP_AT(9);
     }
   }
-  if (MODE == MODE_HG) {
+  if (MODE == MODE_HG || MODE == MODE_G) {
     d.team_sync();
     finish_cost();
   }
@@ -1256,7 +1272,7 @@ DecodeArgs base_decode_args(const vaenmf_plan* p, const float* Zs, int Rcap, int
   DecodeArgs a = {};
   a.dw = make_decw(p);
   a.Zs = Zs; a.B1 = B1; a.frame_utt = p->d_frame_utt;
-  a.Fs = p->Fs; a.K = p->cfg.K; a.NT = p->NT; a.Rcap = Rcap; a.R = R;
+  a.Fs = p->Fs; a.K = p->cfg.K; a.NT = p->NT; a.Rcap = Rcap; a.R = R; a.Vb = p->Vb_ext;
   return a;
 }
 
@@ -1282,7 +1298,7 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
   VN_REQUIRE(rng->mode == VAENMF_RNG_DEVICE || (rng->eps && rng->u), "replay mode needs eps and u buffers");
   ChainArgs a = {};
   a.dw = make_decw(p);
-  a.X2 = X2; a.W = W; a.Ht = Ht; a.g = g; a.B1 = B1; a.Z = Z; a.Zs = Zs; a.acc_out = acc_out;
+  a.X2 = X2; a.W = W; a.Ht = Ht; a.g = g; a.B1 = B1; a.Z = Z; a.Zs = Zs; a.acc_out = acc_out; a.Vb = p->Vb_ext;
   a.tile_utt = p->d_tile_utt; a.tile_n0 = p->d_tile_n0; a.tile_cnt = p->d_tile_cnt; a.frame_off = p->d_frame_off;
   a.utt_seed = p->d_utt_seed; a.eps = rng->eps; a.u = rng->u;
   a.Fs = p->Fs; a.Kp = p->Kp; a.NT = p->NT; a.Rcap = Rcap; a.nsamples = nsamples; a.burnin = burnin;
@@ -1326,6 +1342,12 @@ extern "C" int vaenmf_m_step(vaenmf_plan* p, const float* X2, float* W, float* H
   DecodeArgs a = base_decode_args(p, Zs, Rcap, R, B1);
   a.X2 = X2; a.W = W; a.Ht = Ht; a.g = g; a.A1 = p->A1; a.P = p->P; a.normW = p->normW;
   a.cost_frames = cost_frames ? cost_frames : p->cost_frames;
+  if (p->Vb_ext) {                                      // noNMF: only the gains move (mcem.py:543-578)
+    ProfScope ps(p, VN_K_HG, st);
+    launch_decode<MODE_G>(p, a, st);
+    VN_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   { ProfScope ps(p, VN_K_WSTATS, st); launch_decode<MODE_WSTATS>(p, a, st); }   // A1, X2*A2 per (frame, bin)
   { ProfScope ps(p, VN_K_WUPDATE, st); if (int e = vn_launch_w_update(p, W, Ht, st)) return e; }  // W <- W sqrt(num/den), L1 norms
   { ProfScope ps(p, VN_K_HG, st); launch_decode<MODE_HG>(p, a, st); }           // H, g, cost
@@ -1373,3 +1395,9 @@ extern "C" int vaenmf_debug_stamps(long long* out64, int reset) {
   return 0;
 }
 #endif
+
+extern "C" int vaenmf_set_noise_psd(vaenmf_plan* p, const float* Vb) {
+  VN_REQUIRE(p != nullptr, "null plan");
+  p->Vb_ext = Vb;
+  return 0;
+}

@@ -95,6 +95,7 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   p->b1 = p->b2 = p->b3 = p->w1y = p->w3n = nullptr;
   p->Dy = 0;
   p->have_weights = false;
+  p->Vb_ext = nullptr;
   p->n_utt = p->NT = p->n_tiles = 0;
   p->prof_on = false;
   p->prof_used = 0;

@@ -162,6 +162,11 @@ class BatchEngine:
         w, b = layers[-1]
         return self.dense(h, t(w), t(b), _lib.ACT_SIGMOID), self.dense(h, t(w), t(b), _lib.ACT_STEP)
 
+    def set_noise_psd(self, Vb):
+        """Fixed noise variance (the *_noNMF variants, mcem.py:493-760): Vb device float32 [NT,Fs] or None."""
+        self._Vb_ext = None if Vb is None else Vb.to(self.device, torch.float32).contiguous()
+        check(lib().vaenmf_set_noise_psd(self._plan, _ptr(self._Vb_ext)))
+
     def set_labels(self, y):
         """y device float32 [NT,Dy]: fold the label half of the first decoder layer."""
         if self.Dy == 0:

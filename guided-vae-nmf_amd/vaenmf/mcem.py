@@ -199,3 +199,44 @@ class MCEM_M2(_MCEM):
 
     def init_parameters(self, X, y, vae, nmf_rank, eps, device):
         self._init(X, y, vae, nmf_rank, eps, device)
+
+
+class MCEM_M2_noNMF(_MCEM):
+    """Reference surface of MCEM_M2_noNMF (mcem.py:606-760): constructor-style, the noise variance Vb is
+    given and fixed, only the gains are updated.  X complex (N,F), Vb (N,F), g (N,), Z (N,L), y (N,Dy)."""
+    model = "M2"
+
+    def __init__(self, X, Vb, g, Z, y, vae, niter, device, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25,
+                 burnin_WF=75, var_RW=0.01, rng="replay", precision="bf16x3"):
+        super().__init__(niter, nsamples_E_step, burnin_E_step, nsamples_WF, burnin_WF, var_RW, rng=rng, precision=precision)
+        if type(vae).__name__ == "RVAE":
+            raise NameError("MCEM algorithm only valid for FFNN VAE")          # mcem.py:614-615
+        dev = torch.device(device if device not in (None, "cpu") else "cuda:0")
+        N, F = X.shape
+        sd = _state(vae)
+        ns_e, _ = self.e_step_counts()
+        ns_w, _ = self.wf_counts()
+        self.device, self.vae = dev, vae
+        eng = BatchEngine(F, 1, decoder_params_from_state(sd), precision=precision, device=dev, max_frames=N, max_utts=1)
+        eng.bind([N], Rcap=max(ns_e, ns_w))
+        self._eng, self._N, self._F, self._K = eng, N, F, 1
+        self.X = X.T                                                           # mcem.py:503
+        eng.set_spectrogram([np.asarray(X, dtype=np.complex64)])
+        vb = torch.zeros(N, eng.Fs, dtype=torch.float32)
+        vb[:, :F] = torch.as_tensor(np.asarray(Vb), dtype=torch.float32)
+        eng.set_noise_psd(vb)                                                  # mcem.py:507
+        eng.g.copy_(torch.as_tensor(g, dtype=torch.float32).reshape(N))
+        eng.Z.copy_(torch.as_tensor(Z, dtype=torch.float32).reshape(N, LAT))   # mcem.py:617
+        yy = torch.as_tensor(y, dtype=torch.float32).to(dev).reshape(N, -1).contiguous()
+        eng.set_labels(yy)
+        self.y = torch.t(yy)
+        self._call = 0
+
+    @property
+    def Vb(self):
+        return self._eng._Vb_ext[:, :self._F].T
+
+    def run(self):
+        if self.rng == "device":
+            raise NotImplementedError("the fused driver runs the NMF model; use rng='replay' stepping for noNMF")
+        return super().run()

@@ -98,6 +98,11 @@ int vaenmf_bind_batch(vaenmf_plan* p, int32_t n_utt, const int32_t* frame_offset
  * y DEV [NT][Dy]. */
 int vaenmf_layer1_bias(vaenmf_plan* p, const float* y, int32_t Dy, float* B1, void* stream);
 
+/* Fixed noise variance for the *_noNMF variants (EM_noNMF / MCEM_M2_noNMF, mcem.py:493-760): Vb DEV [NT][Fs]
+ * (caller-owned, must stay valid) replaces W H in every later call and vaenmf_m_step then updates the gains only
+ * (mcem.py:543-578); NULL restores the NMF noise model. */
+int vaenmf_set_noise_psd(vaenmf_plan* p, const float* Vb);
+
 /* Metropolis-Hastings chain of one E-step / Wiener phase -- replaces
  * MCEM_M1.sample_posterior (mcem.py:371-441) and MCEM_M2.sample_posterior (:218-294):
  * nsamples+burnin random-walk steps per frame, samples after burn-in to Zs[:, 0..nsamples-1, :].

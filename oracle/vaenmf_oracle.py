@@ -363,6 +363,33 @@ class MCEMOracle:
         return cost
 
 
+class MCEMOracleNoNMF(MCEMOracle):
+    """EM_noNMF + MCEM_M2_noNMF (mcem.py:493-760): the noise variance Vb is given and fixed, only the
+    gains g are updated.  Constructor-style API like the reference (:608-629): X complex (N,F), Vb (N,F),
+    g (N,), Z (N,L), y (N,Dy)."""
+
+    def __init__(self, X, Vb, g, Z, y, params, niter, rng, nsamples_E_step=10, burnin_E_step=30,
+                 nsamples_WF=25, burnin_WF=75, var_RW=0.01):
+        super().__init__("M2", niter, nsamples_E_step, burnin_E_step, nsamples_WF, burnin_WF, var_RW)
+        self.rng, self.params = rng, params
+        self.X = X.T                                             # mcem.py:503
+        self.X_abs_2 = (np.abs(X.T) ** 2).astype(f32)            # :504
+        self.Vb = np.asarray(Vb, f32).T.copy()                   # :507
+        self.g = np.asarray(g, f32).copy()                       # :508
+        self.Z = np.asarray(Z, f32).T.copy()                     # :617
+        self.y = np.asarray(y, f32).T.copy()                     # :618
+        self.L = self.Z.shape[0]
+        self.Vs = self.Vs_scaled = self.Vx = None
+
+    def M_step(self):                                            # mcem.py:543-578
+        self.compute_Vx()
+        iv = _inv(self.Vx)
+        num = np.sum(self.X_abs_2 * np.sum(self.Vs * iv * iv, 0), 0)
+        den = np.sum(np.sum(self.Vs * iv, 0), 0)
+        self.g = (self.g * np.sqrt(num / den)).astype(f32)
+        self.compute_Vs_scaled(); self.compute_Vx()
+
+
 # ----------------------------------------------------------------------------
 # STFT / iSTFT (python/processing/stft.py -> librosa.core.stft/istft)
 # ----------------------------------------------------------------------------

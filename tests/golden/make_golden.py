@@ -158,6 +158,40 @@ def run_case(name, model, F, N, K, dims_h, L, niter, counts, Dy=0, seed=0, n_try
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **best[1])
 
 
+def nonmf_case():
+    """MCEM_M2_noNMF (mcem.py:606-760): fixed noise variance, gains only."""
+    F, N, L, Dy, H, niter = 65, 16, 32, 1, [128, 128], 3
+    counts = (5, 7, 6, 9)
+    best = None
+    for t in range(30):
+        sd = 77 + 1000 * t
+        params = orc.xavier_normal_params([F, L, H], seed=sd, y_dim=Dy, bias_std=0.05)
+        vae = ref_models.DeepGenerativeModel([F, Dy, L, H], None)
+        vae.load_state_dict(to_state(params)); vae.eval()
+        g0 = np.random.default_rng(sd + 3)
+        X = make_X(N, F, sd + 1)
+        Vb = (0.2 + g0.random((N, F))).astype(np.float32)
+        gains = (0.5 + g0.random(N)).astype(np.float32)
+        Z0 = (0.5 * g0.standard_normal((N, L))).astype(np.float32)
+        y = (g0.random((N, Dy)) > 0.5).astype(np.float32)
+        torch.manual_seed(sd)
+        with torch.no_grad(), Recorder() as rec:
+            m = ref_mcem.MCEM_M2_noNMF(X=X, Vb=Vb, g=torch.tensor(gains), Z=torch.tensor(Z0), y=torch.tensor(y), vae=vae,
+                                       niter=niter, device="cpu", nsamples_E_step=counts[0], burnin_E_step=counts[1],
+                                       nsamples_WF=counts[2], burnin_WF=counts[3], var_RW=0.01)
+            cost = m.run()
+        us = [d for d, k in zip(rec.draws, rec.kinds) if k == "u" and d.ndim == 1]
+        margins = np.concatenate([np.abs(np.log(u) - a) for u, a in zip(us, rec.acc)])
+        mm = float(margins.min())
+        if best is None or mm > best[0]:
+            best = (mm, dict(X=X, Vb=Vb, g0=gains, Z0=Z0, y=y, cost=cost, g=m.g.numpy(), Z=m.Z.numpy(),
+                             S_hat=m.S_hat.astype(np.complex64), N_hat=m.N_hat.astype(np.complex64), acc=np.stack(rec.acc),
+                             meta=np.array([F, N, 0, L, Dy, niter, *counts], dtype=np.int64), min_margin=np.float64(mm),
+                             **{"p:" + k: v for k, v in params.items()}, **pack_draws("d", rec.draws)))
+    print("m2_nonmf_f65: min decision margin %.3e (%d decisions)" % (best[0], best[1]["acc"].size))
+    np.savez_compressed(os.path.join(HERE, "m2_nonmf_f65.npz"), **best[1])
+
+
 def quirk_case():
     """Reference-faithful default counts: assert the positional-shift quirk
     (mcem.py:371 vs :461-462, :477-478): M1 runs S/R = 60/30 and 105/75;

@@ -457,3 +457,28 @@ def test_file_driver_ragged_batch(tmp_path):
         assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
     # same utterance seed => identical result whatever the batch composition (first file: same seed in both runs)
     assert np.array_equal(wavio.read(w_all[0][0])[0], wavio.read(w_one[0][0])[0])
+
+
+def test_nonmf_variant_against_reference():
+    """MCEM_M2_noNMF drop-in (mcem.py:606-760) with replayed noise against the reference's recorded run."""
+    need_gpu()
+    import vaenmf
+    z, params, draws, meta = load_case("m2_nonmf_f65")
+    nsE, biE, nsW, biW = meta["counts"]
+    vae = vaenmf.DeepGenerativeModel([meta["F"], meta["Dy"], meta["L"], [128, 128]], None)
+    vae.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+    it = iter(draws)
+    _r, _n = torch.rand, torch.randn
+    torch.rand = lambda *s, **k: torch.tensor(next(it))
+    torch.randn = lambda *s, **k: torch.tensor(next(it))
+    try:
+        m = vaenmf.MCEM_M2_noNMF(X=z["X"], Vb=z["Vb"], g=torch.tensor(z["g0"]), Z=torch.tensor(z["Z0"]), y=torch.tensor(z["y"]),
+                                 vae=vae, niter=meta["niter"], device="cuda:0", nsamples_E_step=nsE, burnin_E_step=biE,
+                                 nsamples_WF=nsW, burnin_WF=biW, var_RW=0.01)
+        cost = m.run()
+    finally:
+        torch.rand, torch.randn = _r, _n
+    assert np.max(np.abs(cost - z["cost"]) / np.abs(z["cost"])) < 2e-4
+    assert rel_err(m.g.cpu().numpy(), z["g"]) < 2e-3
+    assert np.max(np.abs(m.Z.cpu().numpy() - z["Z"])) < 1e-5
+    assert nrm_err(m.S_hat, z["S_hat"]) < 2e-3 and nrm_err(m.N_hat, z["N_hat"]) < 2e-3

@@ -114,3 +114,16 @@ def test_stft_roundtrip_and_shapes():
     assert Xa.shape == (257, 501)
     with pytest.raises(ValueError):
         orc.stft(x, fs=16000, wlen_sec=50.01e-3)
+
+
+def test_nonmf_variant_full_run():
+    """MCEM_M2_noNMF (mcem.py:606-760): fixed noise variance, gain-only M-step (:543-578)."""
+    z, params, draws, meta = load_case("m2_nonmf_f65")
+    nsE, biE, nsW, biW = meta["counts"]
+    rng = orc.ReplayRNG(draws)
+    m = orc.MCEMOracleNoNMF(z["X"], z["Vb"], z["g0"], z["Z0"], z["y"], params, meta["niter"], rng, nsE, biE, nsW, biW, 0.01)
+    cost = m.run()
+    assert rng.pos == len(rng.draws)
+    assert np.max(np.abs(cost - z["cost"]) / np.abs(z["cost"])) < 2e-5
+    assert rel_err(m.g, z["g"]) < 2e-4 and np.max(np.abs(m.Z - z["Z"])) < 2e-5
+    assert nrm_err(m.S_hat, z["S_hat"]) < 1e-5 and nrm_err(m.N_hat, z["N_hat"]) < 1e-5
