@@ -493,13 +493,17 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
 #pragma unroll
           for (int fg = 0; fg < 2; ++fg) {
             const f32x4 acc = fg == 0 ? acc0 : acc1;
+            // two bins at a time: log Vx0 + log Vx1 = log(Vx0 Vx1) and X0/Vx0 + X1/Vx1 = (X0 Vx1 + X1 Vx0)/(Vx0 Vx1)
+            // share one product, one log and one reciprocal (variances outside 1e-19..1e19 have no fp32 square
+            // in the M-step either)
             float pl = 0.f, px = 0.f;                       // sum log2 Vx, sum X2 / Vx
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float vs = fast_exp(acc[t]);
-              const float vx = gn[fg] * vs + vb[i][fg][t];
-              pl += fast_log2(vx);
-              px += x2[i][fg][t] * fast_rcp(vx);
+            for (int t = 0; t < 4; t += 2) {
+              const float v0 = gn[fg] * fast_exp(acc[t]) + vb[i][fg][t];
+              const float v1 = gn[fg] * fast_exp(acc[t + 1]) + vb[i][fg][t + 1];
+              const float pp = v0 * v1;
+              pl += fast_log2(pp);
+              px += (x2[i][fg][t] * v1 + x2[i][fg][t + 1] * v0) * fast_rcp(pp);
             }
             e[fg] += (double)(pl * LN2_F + px);
           }
@@ -622,9 +626,10 @@ struct DecodeArgs {
   float *Ht, *g;                       // read (and written by MODE_HG)
   float *Vs_out, *A1, *P, *S_hat, *N_hat, *WFs, *WFn;
   double* cost_frames;
-  const int32_t* frame_utt;
-  int Fs, K, NT, Rcap, R;
+  const int32_t *tile_utt, *tile_n0, *tile_cnt;   // frame tiles (<= 32 NTEAM frames of one utterance each)
+  int Fs, K, NT, Rcap, R, n_tiles;
   int w3_lds_off;
+  int wl_lds_off;                      // LDS offset of the staged W[utt] (rank <= 8)
 };
 
 struct DecodeX {            // one per team
@@ -656,20 +661,38 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
     fidx[i] = 16 * t16 + c;
     fval[i] = d.tile_ok(i) && fidx[i] < dw.Fm;
   }
-  // contiguous chunk of frames per workgroup; the teams take alternate frames of the chunk
-  const int per = (a.NT + gridDim.x - 1) / gridDim.x;
-  const int n_beg = blockIdx.x * per, n_end = (n_beg + per < a.NT) ? n_beg + per : a.NT;
+  // Rank <= 8: the utterance's W (Fs x 8 floats) sits in LDS (every lane reads its bins' rows several times
+  // per frame; from L2 each read is an exposed ~2 us round trip for a team that has nothing else to run).
+  constexpr bool WLDS = (KP == 8) && MODE != MODE_STORE && MODE != MODE_G;
+  float* wl = reinterpret_cast<float*>(smem + a.wl_lds_off);
 
-  // Inputs of one frame, loaded one iteration ahead so their HBM/L2 latency hides under the
-  // previous frame's decode (a team has nothing else to switch to while it waits).
+  // Inputs of one frame.  The ones layer 1 needs at once (latents, M2: the folded layer-1 bias) are loaded
+  // one frame ahead, under the previous frame's decode; the rest is issued at the top of the frame and
+  // first used after the hidden layers.
   struct FrameIn {
     float zz[2][8];        // first 32 samples' latents, fragment order
+    f32x4 b1v[TPW];        // layer-1 accumulator init (M2)
+  };
+  struct FrameLate {
     float x2f[MT];
     float hrow[KP];
     float g;
     float x2n;             // X2 of the odd last bin
-    int utt;
   };
+  f32x4 bias1_m1[TPW];                             // M1: the layer-1 bias is the same for every frame
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti) bias1_m1[ti] = *reinterpret_cast<const f32x4*>(dw.b1 + 16 * (w + NW * ti) + 4 * q);
+
+  // one tile (frames of one utterance) at a time; the teams take alternate frames of the tile
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+  const int utt = a.tile_utt[tile];
+  const int n_beg = a.tile_n0[tile], n_end = n_beg + a.tile_cnt[tile];
+  if (WLDS) {
+    if (tile != (int)blockIdx.x) __syncthreads();          // every wave is done with the previous tile's W
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.W + (size_t)utt * a.Fs * KP);
+    for (int e = threadIdx.x; e < a.Fs * KP / 4; e += blockDim.x) reinterpret_cast<f32x4*>(wl)[e] = src[e];
+    __syncthreads();
+  }
   auto frame_of = [&](int nb, bool& on) {
     on = nb + d.team < n_end;                   // team without a frame shadows the last one, stores masked
     return on ? nb + d.team : n_end - 1;
@@ -688,7 +711,11 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
   };
   auto load_frame = [&](int n, FrameIn& f) {
     load_z(n, 0, f.zz);
-    f.utt = a.frame_utt[n];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti)
+      f.b1v[ti] = a.B1 ? *reinterpret_cast<const f32x4*>(a.B1 + (size_t)n * HID + 16 * (w + NW * ti) + 4 * q) : bias1_m1[ti];
+  };
+  auto load_late = [&](int n, FrameLate& f) {
     if (MODE != MODE_STORE) {
       f.g = a.g[n];
       f.x2n = d.nyq ? a.X2[(size_t)n * a.Fs + dw.F - 1] : 0.f;
@@ -702,23 +729,14 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
       }
     }
   };
-  // Loading the next frame's inputs one iteration ahead was tried: the second register set pushed the
-  // kernels over 256 VGPRs (spills) and lost more than the hidden latency won (HG 0.79 -> 0.67 ms without).
-  constexpr bool PREFETCH = false;
-  f32x4 bias1_m1[TPW];                             // M1: the layer-1 bias is the same for every frame
-#pragma unroll
-  for (int ti = 0; ti < TPW; ++ti) bias1_m1[ti] = *reinterpret_cast<const f32x4*>(dw.b1 + 16 * (w + NW * ti) + 4 * q);
+  // (MODE_HG keeps every sample variance of the frame in registers: the second input set only fits at rank 8, bf16)
+  constexpr bool HEAVY = MODE == MODE_HG || MODE == MODE_G;
+  constexpr bool PREFETCH = HEAVY ? (!SPLIT && KP == 8) : true;
   FrameIn nxt;
   if (PREFETCH) {
     bool on0;
-    load_frame(frame_of(n_beg < n_end ? n_beg : 0, on0), nxt);
+    load_frame(frame_of(n_beg, on0), nxt);
   }
-  // rows of W of this lane's bins, cached per utterance when the rank is small (K <= 8)
-  // register budget: bf16x3 streams W3 hi+lo through registers and MODE_HG keeps all sample variances: no room
-  constexpr bool WCACHE = (KP == 8) && !SPLIT && MODE != MODE_HG && MODE != MODE_G;
-  float wreg[WCACHE ? MT : 1][KP];
-  int wutt = -1;
-
   int pend_n = -1, pend_par = 0, cpar = 0;        // MODE_HG: frame whose cost partials wait in LDS
   auto finish_cost = [&]() {
     if ((MODE == MODE_HG || MODE == MODE_G) && pend_n >= 0 && w == 0 && lane == 0) {
@@ -733,16 +751,17 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
     const int n = frame_of(nb, on);
     if (!PREFETCH) load_frame(n, nxt);
     const FrameIn cur = nxt;
+    FrameLate late;
+    load_late(n, late);
     if (PREFETCH && nb + NTEAM < n_end) {
       bool on2;
       load_frame(frame_of(nb + NTEAM, on2), nxt);
     }
     VN_STAMP_DECL
-    const int utt = cur.utt;
     f32x4 bias1[TPW][2];
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
-      bias1[ti][0] = a.B1 ? *reinterpret_cast<const f32x4*>(a.B1 + (size_t)n * HID + 16 * (w + NW * ti) + 4 * q) : bias1_m1[ti];
+      bias1[ti][0] = cur.b1v[ti];
       bias1[ti][1] = bias1[ti][0];
     }
     // decode 32 samples (chunk ch) of frame n: vs[i][sg][t] = Vs(sample 32ch+16sg+4q+t, bin fidx[i])
@@ -753,6 +772,58 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
 #pragma unroll
       for (int t = 0; t < 4; ++t) mk[sg][t] = (16 * sg + 4 * q + t < a.R) ? 1.f : 0.f;
     auto rvalid = [&](int ch, int sg, int t) { return 32 * ch + 16 * sg + 4 * q + t < a.R; };
+    // ---- per-bin constants of frame n: X2, rows of W, Vb = sum_k W[f,k] H[k,n]
+    // (computing them after the hidden layers, when their loads have surely landed, measured slower:
+    // wstats 0.316 -> 0.330 ms, H/g 0.602 -> 0.614 ms)
+    const float gn_late = late.g;
+    float x2f[MAXT], vb[MAXT];
+    auto wrow = [&](int i, int k) {   // 4 consecutive ranks of W[utt][fidx[i]][:]
+      if (WLDS) return *reinterpret_cast<const f32x4*>(wl + fidx[i] * KP + k);
+      return *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + fidx[i]) * Kp + k);
+    };
+    auto dotWH = [&](int i, const float (&hvec)[KP]) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < Kp; k += 4) {
+        const f32x4 ww = wrow(i, k);
+        v += ww[0] * hvec[k] + ww[1] * hvec[k + 1] + ww[2] * hvec[k + 2] + ww[3] * hvec[k + 3];
+      }
+      return v;
+    };
+    // W[utt][F-1][:] (odd last bin), re-read at its three uses (same address in every lane: one L1 line)
+    auto wn4 = [&](int k) {
+      if (WLDS) return *reinterpret_cast<const f32x4*>(wl + (dw.F - 1) * KP + k);
+      return *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + dw.F - 1) * Kp + k);
+    };
+    float hs[KP];   // H[:,n] (MODE_HG: times the pending column norms of W)
+    float vbn = 1.f, gn = 1.f, x2n = 0.f;
+    if (MODE != MODE_STORE) {
+      gn = gn_late;
+      x2n = late.x2n;
+#pragma unroll
+      for (int k = 0; k < Kp; k += 4) {
+        f32x4 nv = {1.f, 1.f, 1.f, 1.f};
+        if (MODE == MODE_HG) nv = *reinterpret_cast<const f32x4*>(a.normW + (size_t)utt * Kp + k);   // (MODE_G: H is not used)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) hs[k + t] = late.hrow[k + t] * nv[t];
+      }
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) {
+        const bool tv = d.tile_ok(i);
+        x2f[i] = late.x2f[i];
+        vb[i] = !tv ? 1.f : (a.Vb ? a.Vb[(size_t)n * a.Fs + fidx[i]] : dotWH(i, hs));
+      }
+      if (d.nyq && a.Vb) {
+        vbn = a.Vb[(size_t)n * a.Fs + dw.F - 1];
+      } else if (d.nyq) {
+        vbn = 0.f;
+#pragma unroll
+        for (int k = 0; k < Kp; k += 4) {
+          const f32x4 ww = wn4(k);
+          vbn += ww[0] * hs[k] + ww[1] * hs[k + 1] + ww[2] * hs[k + 2] + ww[3] * hs[k + 3];
+        }
+      }
+    }
     // decode 32 samples (chunk ch) of frame n; each finished bin tile i is handed to epi(i, vs0, vs1) with
     // vs_sg[t] = Vs(sample 32ch+16sg+4q+t, bin fidx[i]) so its VALU work overlaps the next tile's MFMAs
     auto decode_tiles = [&](int ch, auto epi) {
@@ -826,64 +897,6 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
         }
       }
       continue;
-    }
-
-    // ---- per-bin constants of frame n: X2, rows of W, Vb = sum_k W[f,k] H[k,n]
-    const float gn = cur.g;
-    float x2f[MAXT], vb[MAXT];
-    if (WCACHE && utt != wutt) {        // wave-uniform: all lanes of a team share the frame
-      wutt = utt;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int k = 0; k < Kp; k += 4) {
-          const f32x4 ww = (d.tile_ok(i)) ? *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + fidx[i]) * Kp + k)
-                                                 : f32x4{0, 0, 0, 0};
-#pragma unroll
-          for (int t = 0; t < 4; ++t) wreg[WCACHE ? i : 0][k + t] = ww[t];
-        }
-    }
-    auto wrow = [&](int i, int k) {   // 4 consecutive ranks of W[utt][fidx[i]][:]
-      if (WCACHE) return f32x4{wreg[WCACHE ? i : 0][k], wreg[WCACHE ? i : 0][k + 1], wreg[WCACHE ? i : 0][k + 2], wreg[WCACHE ? i : 0][k + 3]};
-      return *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + fidx[i]) * Kp + k);
-    };
-    auto dotWH = [&](int i, const float (&hvec)[KP]) {
-      float v = 0.f;
-#pragma unroll
-      for (int k = 0; k < Kp; k += 4) {
-        const f32x4 ww = wrow(i, k);
-        v += ww[0] * hvec[k] + ww[1] * hvec[k + 1] + ww[2] * hvec[k + 2] + ww[3] * hvec[k + 3];
-      }
-      return v;
-    };
-    float hs[KP];   // H[:,n] (MODE_HG: times the pending column norms of W)
-#pragma unroll
-    for (int k = 0; k < Kp; k += 4) {
-      f32x4 nv = {1.f, 1.f, 1.f, 1.f};
-      if (MODE == MODE_HG) nv = *reinterpret_cast<const f32x4*>(a.normW + (size_t)utt * Kp + k);   // (MODE_G: H is not used)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) hs[k + t] = cur.hrow[k + t] * nv[t];
-    }
-#pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      const bool tv = d.tile_ok(i);
-      x2f[i] = cur.x2f[i];
-      vb[i] = !tv ? 1.f : (a.Vb ? a.Vb[(size_t)n * a.Fs + fidx[i]] : dotWH(i, hs));
-    }
-
-    // W[utt][F-1][:] (odd last bin), re-read at its three uses (same address in every lane: one L1 line)
-    auto wn4 = [&](int k) { return *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + dw.F - 1) * Kp + k); };
-    float vbn = 1.f;
-    const float x2n = cur.x2n;
-    if (d.nyq && a.Vb) {
-      vbn = a.Vb[(size_t)n * a.Fs + dw.F - 1];
-    } else if (d.nyq) {
-      vbn = 0.f;
-#pragma unroll
-      for (int k = 0; k < Kp; k += 4) {
-        const f32x4 ww = wn4(k);
-        vbn += ww[0] * hs[k] + ww[1] * hs[k + 1] + ww[2] * hs[k + 2] + ww[3] * hs[k + 3];
-      }
     }
 
     if (MODE == MODE_WSTATS) {
@@ -1183,6 +1196,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
     d.team_sync();
     finish_cost();
   }
+  }   // tiles
 }
 
 }  // namespace
@@ -1243,7 +1257,11 @@ void launch_decode_one(const DecodeArgs& a, int grid, size_t lds, hipStream_t st
 template <int NW, int NTEAM, int MT, bool SPLIT, int MODE>
 int launch_decode_kp(DecodeArgs a, int Kp, int grid, hipStream_t st) {
   size_t lds;
-  lds_plan<NTEAM, SPLIT>(a.dw.NT3, sizeof(DecodeX), &a.w3_lds_off, &lds);
+  // per team: DecodeX; per workgroup: the staged W[utt] (rank <= 8), placed right after the DecodeX blocks
+  const size_t wl_bytes = (Kp == 8 && MODE != MODE_STORE && MODE != MODE_G) ? (size_t)a.Fs * 8 * sizeof(float) : 0;
+  const size_t x_bytes = (NTEAM * sizeof(DecodeX) + 15) / 16 * 16;
+  lds_plan<NTEAM, SPLIT>(a.dw.NT3, (x_bytes + wl_bytes + NTEAM - 1) / NTEAM, &a.w3_lds_off, &lds);
+  a.wl_lds_off = (int)(LdsMap<NTEAM, SPLIT>::common_end + x_bytes);
   switch (Kp) {
     case 8:  launch_decode_one<NW, NTEAM, MT, SPLIT, MODE, 8>(a, grid, lds, st); break;
     case 16: launch_decode_one<NW, NTEAM, MT, SPLIT, MODE, 16>(a, grid, lds, st); break;
@@ -1257,7 +1275,7 @@ int launch_decode_kp(DecodeArgs a, int Kp, int grid, hipStream_t st) {
 template <int MODE>
 int launch_decode(const vaenmf_plan* p, const DecodeArgs& a, hipStream_t st) {
   const int want = p->n_sms * 2;
-  const int grid = a.NT < want ? a.NT : want;
+  const int grid = a.n_tiles < want ? a.n_tiles : want;
   const bool split = p->cfg.precision == VAENMF_PREC_BF16X3;
   const int Kp = (MODE == MODE_STORE) ? 8 : p->Kp;
   switch (p->geom) {
@@ -1271,7 +1289,7 @@ int launch_decode(const vaenmf_plan* p, const DecodeArgs& a, hipStream_t st) {
 DecodeArgs base_decode_args(const vaenmf_plan* p, const float* Zs, int Rcap, int R, const float* B1) {
   DecodeArgs a = {};
   a.dw = make_decw(p);
-  a.Zs = Zs; a.B1 = B1; a.frame_utt = p->d_frame_utt;
+  a.Zs = Zs; a.B1 = B1; a.tile_utt = p->d_tile_utt; a.tile_n0 = p->d_tile_n0; a.tile_cnt = p->d_tile_cnt; a.n_tiles = p->n_tiles;
   a.Fs = p->Fs; a.K = p->cfg.K; a.NT = p->NT; a.Rcap = Rcap; a.R = R; a.Vb = p->Vb_ext;
   return a;
 }

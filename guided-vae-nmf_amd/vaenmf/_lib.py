@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvaenmf.so")
+LIB_PATH = os.environ.get("VAENMF_LIB") or os.path.join(_HERE, "libvaenmf.so")   # VAENMF_LIB: another build of the same library (dev A/B runs)
 
 PREC_BF16X3, PREC_BF16 = 0, 1
 RNG_REPLAY, RNG_DEVICE = 0, 1

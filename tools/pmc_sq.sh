@@ -1,0 +1,27 @@
+#!/bin/bash
+# dev aid (GPU box): three SQ counter passes over a short bench run; prints per-kernel ratios
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/pmcsq
+rm -rf $OUT; mkdir -p $OUT
+ARGS="bench.py --steps 1 --warmup 0 --niter 6 --no-cpu-baseline --no-parity-mode --precision ${1:-bf16}"
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/a -- python $ARGS > $OUT/a.log 2>&1 &&
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_LDS_UNALIGNED_STALL --output-format csv -d $OUT/b -- python $ARGS > $OUT/b.log 2>&1 &&
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/c -- python $ARGS > $OUT/c.log 2>&1 &&
+python - <<'PY'
+import csv, glob, collections
+short = lambda k: k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
+for p in "abc":
+    fs = glob.glob("gpurun_out/pmcsq/%s/*/*_counter_collection.csv" % p)
+    if not fs: print("no csv for pass", p); continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); nd = collections.defaultdict(set); dur = collections.defaultdict(float)
+    for r in csv.DictReader(open(fs[0])):
+        k = short(r["Kernel_Name"])
+        if not any(s in k for s in ("mh_chain", "decode_kernel")): continue
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); nd[k].add(r["Dispatch_Id"])
+        dur[(k, r["Dispatch_Id"])] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    for k in agg:
+        n = len(nd[k]); t = sum(d for (kk, _), d in dur.items() if kk == k) / n
+        print("%s  launches %d  avg %.1f us" % (k, n, t / 1e3))
+        for c in sorted(agg[k]): print("    %-28s %16.0f per launch" % (c, agg[k][c] / n))
+PY
