@@ -10,6 +10,7 @@ PREC_BF16X3, PREC_BF16 = 0, 1
 RNG_REPLAY, RNG_DEVICE = 0, 1
 Q_FS, Q_KP, Q_TILES, Q_NT, Q_NUTT = 0, 1, 2, 3, 4
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID, ACT_STEP = 0, 1, 2, 3, 4
+LABEL_IBM, LABEL_VAD = 0, 1
 
 
 class Config(C.Structure):
@@ -43,6 +44,10 @@ SIGNATURES = {
     "vaenmf_stft_num_frames": (_I, [_I64, _D, _D, _D, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "vaenmf_stft_batch": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "vaenmf_istft_batch": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "vaenmf_lorenz_work_bytes": (_I64, [_I, _I, _I, _I]),
+    "vaenmf_lorenz_labels": (_I, [_P, _I, _P, _I, _I, _I, _F, _F, _F, _P, _I, _P, _P, _I64, _P]),
+    "vaenmf_wiener_mask": (_I, [_P, _P, _I64, _F, _P, _P]),
+    "vaenmf_apply_mask": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "vaenmf_gram3_batch": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "vaenmf_profile_enable": (_I, [_P, _I]),
     "vaenmf_profile_read": (_I, [_P, _P, _P]),

@@ -65,6 +65,53 @@ class Reconstructor:
         return s_hat, n_hat, cost
 
 
+class MaskEnhancer:
+    """Supervised Wiener-mask baseline, the build's counterpart of scripts/evaluate_wiener_filter.py:71-113
+    (process_utt), batched: soft mask = classifier(normalised |X|^2) (ReLU hidden layers, sigmoid output of
+    F units, python/models/models.py:160-185), S_hat = mask * X, iSTFT with max_len = T_orig.
+    classifier = [(W, b) hidden..., (W, b) output] float32 numpy; mean/std (F,1) or None (std_norm False)."""
+
+    def __init__(self, classifier, x_dim, mean=None, std=None, fs=16000, wlen_sec=64e-3, hop_percent=0.25, eps=1e-8,
+                 device="cuda:0"):
+        self.F, self.fs, self.wlen_sec, self.hop_percent, self.eps = int(x_dim), fs, wlen_sec, hop_percent, eps
+        self.device = torch.device(device)
+        layers = [(np.asarray(w, np.float64), np.asarray(b, np.float64)) for w, b in classifier]
+        if mean is not None:                 # (x - mean) / (std + eps) folded into the first layer (:88-90)
+            m = np.asarray(mean, np.float64).reshape(-1)
+            s = np.asarray(std, np.float64).reshape(-1) + eps
+            w0, b0 = layers[0]
+            layers[0] = (w0 / s[None, :], b0 - (w0 / s[None, :]) @ m)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+        self.layers = [(t(w), t(b)) for w, b in layers]
+
+    def enhance(self, wav, sample_counts):
+        """wav device float32 [sum T] -> (s_hat device float32 [sum T], soft mask device float32 [NT][F])."""
+        from ._lib import lib, check, ACT_RELU, ACT_SIGMOID
+        ptr = lambda x: x.data_ptr()
+        st = torch.cuda.current_stream().cuda_stream
+        Fs = (self.F + 15) // 16 * 16
+        X, fc = vstft.stft_batch(wav, sample_counts, self.fs, self.wlen_sec, self.hop_percent, Fs=Fs, device=self.device)
+        NT = X.shape[0]
+        Xr = X                                            # [NT][Fs][2] float32 = complex64
+        X2 = torch.empty(NT, Fs, dtype=torch.float32, device=self.device)
+        check(lib().vaenmf_power_spec(ptr(Xr), ptr(X2), NT * Fs, st))                        # :84
+        h, ld = X2, Fs
+        for i, (w, b) in enumerate(self.layers):
+            out = w.shape[0]
+            y = torch.empty(NT, out, dtype=torch.float32, device=self.device)
+            act = ACT_SIGMOID if i == len(self.layers) - 1 else ACT_RELU
+            check(lib().vaenmf_dense(ptr(h), NT, w.shape[1], ld, ptr(w), ptr(b), out, act, ptr(y), out, st))
+            h, ld = y, out
+        if h.shape[1] != self.F:
+            raise ValueError("the mask classifier must end in F = %d units, got %d" % (self.F, h.shape[1]))
+        S = torch.empty_like(Xr)
+        check(lib().vaenmf_apply_mask(ptr(Xr), ptr(h), self.F, NT, self.F, Fs, ptr(S), st))  # :99
+        nfft, hop = vstft.frame_geometry(sample_counts[0], self.fs, self.wlen_sec, self.hop_percent)[:2]
+        s_hat = vstft.istft_batch(S, fc, sample_counts, nfft, hop, device=self.device)
+        self.frame_counts = fc
+        return s_hat, h
+
+
 def allreduce_stats(stats, device):
     """Sum the metric sufficient statistics over ranks (RCCL when the process group is
     'nccl'); the only collective of the whole job."""

@@ -185,6 +185,34 @@ int vaenmf_istft_batch(const float* S, int32_t n_utt, int32_t n_frames_total,
                        int32_t nfft, int32_t hop, int32_t Fs, float* work, float* wav_out,
                        void* stream);
 
+/* Label / guide front-ends of the M2 path -- replace python/processing/target.py.
+ * vaenmf_lorenz_labels: clean_speech_IBM (target.py:7-28, mode VAENMF_LABEL_IBM) and
+ * clean_speech_VAD (:30-50, mode VAENMF_LABEL_VAD) for a batch of utterances: power =
+ * |X|^2 (VAD: summed over the bins of a frame), descending sort per utterance, Lorenz
+ * curve cumsum/sum, threshold = last sorted power whose Lorenz value is < quantile_fraction,
+ * label = power > threshold ? hi : lo, where lo/hi are the caller's softened and rounded
+ * values round(0.5 -/+ 0.5 quantile_weight) (:24-27).  The float32 arithmetic follows
+ * numpy's operation order, so the 0/1 decisions are those of the reference bit for bit.
+ * X DEV complex64 [NT][Fs]; frame_offsets HOST int32 [n_utt+1]; labels DEV float
+ * [NT][ld] (IBM, bins < F written) or [NT] (VAD); thr_out DEV float [n_utt] or null;
+ * work DEV scratch of vaenmf_lorenz_work_bytes() bytes.  Synchronises the stream; an
+ * utterance with no Lorenz value below the fraction is the reference's IndexError. */
+enum { VAENMF_LABEL_IBM = 0, VAENMF_LABEL_VAD = 1 };
+int64_t vaenmf_lorenz_work_bytes(int32_t n_frames_total, int32_t F, int32_t n_utt, int32_t mode);
+int vaenmf_lorenz_labels(const float* X, int32_t n_utt, const int32_t* frame_offsets, int32_t F,
+                         int32_t Fs, int32_t mode, float quantile_fraction, float lo, float hi,
+                         float* labels, int32_t ld, float* thr_out, void* work,
+                         int64_t work_bytes, void* stream);
+/* ideal_wiener_mask (target.py:104-116): |S|^2 / (|S|^2 + |N|^2 + eps), S, N DEV
+ * complex64 [n], mask DEV float [n]. */
+int vaenmf_wiener_mask(const float* S, const float* N, int64_t n, float eps, float* mask,
+                       void* stream);
+/* Supervised Wiener-mask baseline, scripts/evaluate_wiener_filter.py:99: S_hat = mask * X.
+ * X, S_hat DEV complex64 [NT][Fs]; mask DEV float [NT][ldm] (bins < F read; bins >= F of
+ * S_hat zeroed). */
+int vaenmf_apply_mask(const float* X, const float* mask, int32_t ldm, int32_t NT, int32_t F,
+                      int32_t Fs, float* S_hat, void* stream);
+
 /* SI-SDR sufficient statistics -- python/metrics.py:12-60: per utterance the Gram
  * matrix of (s_hat, s, n) in float64: out DEV [n_utt][6] =
  * {<sh,sh>, <sh,s>, <sh,n>, <s,s>, <s,n>, <n,n>}; sample_offsets DEV int64 [n_utt+1]. */

@@ -504,3 +504,111 @@ def synth_utterance(seed, n_samples=64000, fs=16000):
     nz = nz * np.sqrt(k)
     norm = np.max(np.abs(np.concatenate([s, nz, s + nz])))
     return s / norm, nz / norm, (s + nz) / norm, snr_db
+
+
+# ----------------------------------------------------------------------------
+# Label / guide front-ends (python/processing/target.py)
+# ----------------------------------------------------------------------------
+def pairwise_sum_f32(a):
+    """NumPy's float32 add-reduce over a 1-D run, restated (numpy/_core/src/umath/loops_utils.h.src,
+    pairwise_sum; numpy 2.2 is this image's pinned version): < 8 elements a running sum; <= 128 eight
+    interleaved partial sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus the tail; else split at
+    n/2 rounded down to a multiple of 8.  Pins the order the HIP label kernels must reproduce bit for bit."""
+    a = np.asarray(a, dtype=np.float32)
+    n = len(a)
+    f = np.float32
+    if n < 8:
+        r = f(0.0)
+        for x in a:
+            r = f(r + x)
+        return r
+    if n <= 128:
+        r = [f(a[i]) for i in range(8)]
+        i = 8
+        while i < n - (n % 8):
+            for k in range(8):
+                r[k] = f(r[k] + a[i + k])
+            i += 8
+        res = f(f(f(r[0] + r[1]) + f(r[2] + r[3])) + f(f(r[4] + r[5]) + f(r[6] + r[7])))
+        while i < n:
+            res = f(res + a[i])
+            i += 1
+        return res
+    n2 = n // 2
+    n2 -= n2 % 8
+    return f(pairwise_sum_f32(a[:n2]) + pairwise_sum_f32(a[n2:]))
+
+
+def power_c64(obs):
+    """abs(obs * obs.conj()) of a complex64 array as this image's numpy evaluates it (target.py:16, :37):
+    the product's real part is fma(re, re, round(im*im)), its imaginary part exactly 0."""
+    re = obs.real.astype(np.float64)
+    im2 = (obs.imag.astype(np.float32) * obs.imag.astype(np.float32)).astype(np.float64)
+    return (re * re + im2).astype(np.float32)
+
+
+def lorenz_threshold(power, quantile_fraction):
+    """target.py:18-22 / :39-42: descending sort, Lorenz curve cumsum/sum in float32 (running cumsum,
+    pairwise total), threshold = last sorted value whose Lorenz value is below the fraction."""
+    srt = np.sort(np.asarray(power, np.float32), axis=None)[::-1]
+    total = pairwise_sum_f32(srt)
+    run = np.float32(0.0)
+    thr = None
+    q = np.float32(quantile_fraction)
+    for v in srt:
+        run = np.float32(run + v)
+        if np.float32(run / total) < q:
+            thr = v
+        else:
+            break                      # the curve is non-decreasing: nothing further qualifies
+    if thr is None:
+        raise IndexError("index -1 is out of bounds for axis 0 with size 0")   # what target.py:22 raises
+    return thr
+
+
+def _soften(mask, quantile_weight):
+    """target.py:24-27: 0.5 + w (mask - 0.5), rounded half-to-even, float32."""
+    return np.float32(np.round(0.5 + quantile_weight * (mask.astype(np.float64) - 0.5)))
+
+
+def clean_speech_IBM(observations, quantile_fraction=0.98, quantile_weight=0.999):
+    """target.py:7-28.  observations complex64 (F, N) -> float32 (F, N) in {0,1}."""
+    power = power_c64(observations)
+    return _soften(power > lorenz_threshold(power, quantile_fraction), quantile_weight)
+
+
+def frame_power(observations):
+    """target.py:38: power.sum(axis=0) -- for the (F, N) Fortran-ordered STFT the reference's stft returns,
+    each frame is a contiguous run of F values reduced pairwise."""
+    power = power_c64(observations)
+    return np.array([pairwise_sum_f32(power[:, n]) for n in range(power.shape[1])], dtype=np.float32)
+
+
+def clean_speech_VAD(observations, quantile_fraction=0.98, quantile_weight=0.999):
+    """target.py:30-50 -> float32 (1, N)."""
+    p = frame_power(observations)
+    return _soften(p > lorenz_threshold(p, quantile_fraction), quantile_weight)[None]
+
+
+def noise_robust_clean_speech_VAD(observations, quantile_fraction_begin=0.93, quantile_fraction_end=0.99, quantile_weight=0.999):
+    """target.py:52-76: active from the first frame of the strict VAD up to (excluding) the last frame of the
+    lenient one."""
+    vad = clean_speech_VAD(observations, quantile_fraction_begin, quantile_weight)[0]
+    end = clean_speech_VAD(observations, quantile_fraction_end, quantile_weight)[0]
+    b, e = np.nonzero(vad)[0][0], np.nonzero(end)[0][-1]
+    vad[b:e] = 1
+    return vad[None]
+
+
+def noise_robust_clean_speech_IBM(observations, vad_quantile_fraction_begin=0.93, vad_quantile_fraction_end=0.99,
+                                  ibm_quantile_fraction=0.999, quantile_weight=0.999):
+    """target.py:78-102."""
+    vad = noise_robust_clean_speech_VAD(observations, vad_quantile_fraction_begin, vad_quantile_fraction_end, quantile_weight)
+    return clean_speech_IBM(observations, ibm_quantile_fraction, quantile_weight) * vad
+
+
+def ideal_wiener_mask(speech_tf, noise_tf, eps=1e-8):
+    """target.py:104-116."""
+    sp = np.power(abs(speech_tf), 2)
+    npow = np.power(abs(noise_tf), 2)
+    return sp / (sp + npow + eps)

@@ -297,6 +297,32 @@ def metrics_case():
     np.savez_compressed(os.path.join(HERE, "metrics_dummy_m2.npz"), **out)
 
 
+def labels_case():
+    """python/processing/target.py:7-102 (Lorenz-quantile IBM / VAD labels and their noise-robust
+    variants, ideal Wiener mask) on the clean-speech STFTs of two seeded synthetic utterances
+    (complex64, 512-pt: F=257) -- the call pattern of scripts/create_train_set.py:136-150 and
+    run_metrics_M2.py:141-148."""
+    from python.processing import target as ref_target
+    out = {}
+    for u, (seed, T) in enumerate(((3, 12000), (5, 9000))):
+        s, n, x, _ = orc.synth_utterance(seed, n_samples=T)
+        S = orc.stft(s, fs=16000, wlen_sec=32e-3, hop_percent=0.25)       # complex64 (F, N)
+        Nn = orc.stft(n, fs=16000, wlen_sec=32e-3, hop_percent=0.25)
+        assert S.dtype == np.complex64
+        out["S%d" % u] = S
+        out["N%d" % u] = Nn
+        out["ibm%d" % u] = ref_target.clean_speech_IBM(S, quantile_fraction=0.999, quantile_weight=0.999)
+        out["ibm98_%d" % u] = ref_target.clean_speech_IBM(S)
+        out["vad%d" % u] = ref_target.clean_speech_VAD(S, quantile_fraction=0.999, quantile_weight=0.999)
+        out["vad98_%d" % u] = ref_target.clean_speech_VAD(S)
+        out["nrvad%d" % u] = ref_target.noise_robust_clean_speech_VAD(S)
+        out["nribm%d" % u] = ref_target.noise_robust_clean_speech_IBM(S)
+        out["iwm%d" % u] = ref_target.ideal_wiener_mask(S, Nn)
+        print("labels utt", u, S.shape, "ibm on", out["ibm%d" % u].mean(), "vad on", out["vad%d" % u].mean(),
+              "nrvad on", out["nrvad%d" % u].mean())
+    np.savez_compressed(os.path.join(HERE, "labels_f257.npz"), **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -305,6 +331,7 @@ if __name__ == "__main__":
         sys.exit(0)
     quirk_case()
     mlp_case()
+    labels_case()
     metrics_case()
     # real decoder dims (L=32, H=[128,128]) so the HIP path can run the same cases
     run_case("m1_f65", "M1", F=65, N=16, K=4, dims_h=[128, 128], L=32, niter=3, counts=(10, 6, 25, 8))

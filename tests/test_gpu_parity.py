@@ -9,6 +9,8 @@ Stated tolerances (float32 unless noted):
   * trajectories with replayed noise: decisions identical on the golden cases (they were
     chosen with decision margins >= 1e-3), final S_hat 2e-3 relative (L2).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -482,3 +484,73 @@ def test_nonmf_variant_against_reference():
     assert rel_err(m.g.cpu().numpy(), z["g"]) < 2e-3
     assert np.max(np.abs(m.Z.cpu().numpy() - z["Z"])) < 1e-5
     assert nrm_err(m.S_hat, z["S_hat"]) < 2e-3 and nrm_err(m.N_hat, z["N_hat"]) < 2e-3
+
+
+def test_label_front_ends_bit_exact():
+    """vaenmf.target (csrc/labels.hip) against the reference's own outputs (tests/golden/labels_f257.npz,
+    generated by importing python/processing/target.py): every 0/1 label identical, thresholds identical."""
+    need_gpu()
+    from vaenmf import target
+    z = np.load(os.path.join(GOLDEN, "labels_f257.npz"))
+    for u in (0, 1):
+        S, N = z["S%d" % u], z["N%d" % u]
+        for got, key in ((target.clean_speech_IBM(S, 0.999, 0.999), "ibm%d"), (target.clean_speech_IBM(S), "ibm98_%d"),
+                         (target.clean_speech_VAD(S, 0.999, 0.999), "vad%d"), (target.clean_speech_VAD(S), "vad98_%d"),
+                         (target.noise_robust_clean_speech_VAD(S), "nrvad%d"), (target.noise_robust_clean_speech_IBM(S), "nribm%d")):
+            ref = z[key % u]
+            assert got.shape == ref.shape and got.dtype == ref.dtype, key
+            assert np.array_equal(got, ref), (key, int((got != ref).sum()))
+        # soft mask: float32 tolerance.  (numpy's vectorised abs(complex64) is not the correctly rounded hypot -- it
+        # differs from numpy's own scalar abs by 1 ulp in ~1 % of the entries -- so bit equality is not defined here)
+        assert np.max(np.abs(target.ideal_wiener_mask(S, N) - z["iwm%d" % u])) < 3e-7
+    # the batched entry point: both utterances in one call, thresholds against the oracle
+    Xs = [np.ascontiguousarray(z["S%d" % u].T) for u in (0, 1)]
+    F = Xs[0].shape[1]
+    X = torch.from_numpy(np.concatenate(Xs)).cuda()
+    Xp = torch.zeros(X.shape[0], 272, dtype=torch.complex64, device="cuda")
+    Xp[:, :F] = X
+    for mode, key in (("ibm", "ibm98_%d"), ("vad", "vad98_%d")):
+        y, thr = target.lorenz_labels_batch(Xp, [x.shape[0] for x in Xs], F, mode, want_thresholds=True)
+        y, thr = y.cpu().numpy(), thr.cpu().numpy()
+        o = 0
+        for u, x in enumerate(Xs):
+            ref = z[key % u]
+            p = orc.power_c64(z["S%d" % u])
+            t_ref = orc.lorenz_threshold(p if mode == "ibm" else orc.frame_power(z["S%d" % u]), 0.98)
+            assert thr[u] == t_ref
+            got = y[o:o + x.shape[0]]
+            assert np.array_equal(got.T if mode == "ibm" else got[None], ref)
+            o += x.shape[0]
+    # an utterance whose strongest entry alone exceeds the fraction: the reference raises IndexError
+    one = np.zeros((5, 4), np.complex64)
+    one[2, 1] = 3.0
+    with pytest.raises(RuntimeError, match="index -1 is out of bounds"):
+        target.clean_speech_IBM(one, 0.5)
+
+
+def test_mask_baseline_against_oracle():
+    """MaskEnhancer (scripts/evaluate_wiener_filter.py:71-113) against the numpy restatement: classifier mask,
+    S_hat = mask * X, iSTFT."""
+    need_gpu()
+    from vaenmf.pipeline import MaskEnhancer
+    F, T = 257, 9000
+    clf = orc.xavier_normal_classifier([F, [128, 128, 128, 128, 128], F], seed=4)
+    layers = [(clf["hidden.%d.weight" % i], clf["hidden.%d.bias" % i]) for i in range(5)] + [(clf["output_layer.weight"], clf["output_layer.bias"])]
+    g = np.random.default_rng(2)
+    mean, std = g.random((F, 1)) * 0.1, 0.5 + g.random((F, 1))
+    xs = [orc.synth_utterance(s, n_samples=T + 500 * s)[2] for s in (1, 2)]
+    counts = [len(x) for x in xs]
+    enh = MaskEnhancer(layers, F, mean, std, wlen_sec=32e-3, device="cuda:0")
+    s_hat, mask = enh.enhance(torch.from_numpy(np.concatenate(xs).astype(np.float32)).cuda(), counts)
+    s_hat, mask = s_hat.cpu().numpy(), mask.cpu().numpy()
+    o = n0 = 0
+    for x, c in zip(xs, counts):
+        X = orc.stft(x.astype(np.float32), fs=16000, wlen_sec=32e-3, hop_percent=0.25)          # (F, N)
+        xin = ((np.abs(X.T) ** 2).astype(np.float32) - mean.T) / (std + 1e-8).T
+        m_ref = orc.classifier_forward(clf, xin.astype(np.float32))
+        N = X.shape[1]
+        assert np.max(np.abs(mask[n0:n0 + N] - m_ref)) < 2e-5
+        s_ref = orc.istft((m_ref * X.T).T, fs=16000, wlen_sec=32e-3, hop_percent=0.25, max_len=c)
+        assert nrm_err(s_hat[o:o + c], s_ref) < 2e-5
+        o += c
+        n0 += N

@@ -163,7 +163,9 @@ def test_dropin_import_paths():
         md = importlib.import_module("python.models.models")
         st = importlib.import_module("python.processing.stft")
         me = importlib.import_module("python.metrics")
+        tg = importlib.import_module("python.processing.target")
         assert mc.MCEM_M1.__name__ == "MCEM_M1" and md.VariationalAutoencoder and st.stft and me.energy_ratios
+        assert mc.MCEM_M2_noNMF and tg.clean_speech_IBM and tg.clean_speech_VAD and tg.noise_robust_clean_speech_IBM
     finally:
         for k in list(sys.modules):
             if k == "python" or k.startswith("python."):

@@ -1,6 +1,8 @@
 """CPU: pin the numpy oracle against golden vectors produced by the reference
 itself (tests/golden/make_golden.py).  Tolerances are float32 round-off of two
 different BLAS/libm stacks (torch vs numpy): 2e-5 relative on variances."""
+import os
+
 import numpy as np
 import pytest
 
@@ -127,3 +129,23 @@ def test_nonmf_variant_full_run():
     assert np.max(np.abs(cost - z["cost"]) / np.abs(z["cost"])) < 2e-5
     assert rel_err(m.g, z["g"]) < 2e-4 and np.max(np.abs(m.Z - z["Z"])) < 2e-5
     assert nrm_err(m.S_hat, z["S_hat"]) < 1e-5 and nrm_err(m.N_hat, z["N_hat"]) < 1e-5
+
+
+def test_label_front_ends_against_reference():
+    """python/processing/target.py:7-116 restated with explicit float32 operation order (pairwise total,
+    running cumsum, fma power) -- the order the HIP kernels reproduce -- against the reference's outputs."""
+    z = np.load(os.path.join(GOLDEN, "labels_f257.npz"))
+    for u in (0, 1):
+        S, N = z["S%d" % u], z["N%d" % u]
+        assert np.array_equal(orc.power_c64(S), abs(S * S.conj()))
+        assert np.array_equal(orc.clean_speech_IBM(S, 0.999, 0.999), z["ibm%d" % u])
+        assert np.array_equal(orc.clean_speech_IBM(S), z["ibm98_%d" % u])
+        assert np.array_equal(orc.clean_speech_VAD(S, 0.999, 0.999), z["vad%d" % u])
+        assert np.array_equal(orc.clean_speech_VAD(S), z["vad98_%d" % u])
+        assert np.array_equal(orc.noise_robust_clean_speech_VAD(S), z["nrvad%d" % u])
+        assert np.array_equal(orc.noise_robust_clean_speech_IBM(S), z["nribm%d" % u])
+        assert np.array_equal(orc.ideal_wiener_mask(S, N), z["iwm%d" % u])
+    g = np.random.default_rng(0)
+    for n in (1, 7, 8, 9, 127, 128, 129, 257, 1000, 24415):
+        a = (g.random(n) ** 4 * 1000).astype(np.float32)
+        assert orc.pairwise_sum_f32(a) == np.sum(a), n
