@@ -222,3 +222,73 @@ extern "C" int vaenmf_apply_mask(const float* X, const float* mask, int32_t ldm,
   VN_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+// ============================================================================
+// SPP-based noise PSD / speech-presence estimator (python/models/spp_estimation.py:17-160, Gerkmann &
+// Hendriks 2011): a per-bin recursion over the frames of an utterance, float64 state like the reference
+// (numpy float64 arrays), one thread per (utterance, bin).
+// ============================================================================
+namespace {
+
+struct SppParams { double fixed_smooth, prob_smooth, inv_glr_factor, inv_glr_exp_factor; int num_frames_init; };
+
+// per: [NT][ld] float32 periodogram |Y|^2; spp_out / psd_out float32 [NT][ldo] (either may be null)
+__global__ void spp_kernel(const float* __restrict__ per, int ld, const int* __restrict__ frame_off, int F, SppParams p,
+                           float* __restrict__ spp_out, float* __restrict__ psd_out, int ldo) {
+  const int u = blockIdx.y, f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const int n0 = frame_off[u], n1 = frame_off[u + 1];
+  double old_psd = 0.0, smooth = 0.0;
+  int done = 0;
+  for (int n = n0; n < n1; ++n) {
+    const double y = (double)per[(size_t)n * ld + f];
+    double psd, spp;
+    if (done < p.num_frames_init) {                                     // spp_estimation.py:105-117
+      old_psd = old_psd + y / (double)p.num_frames_init;
+      ++done;
+      psd = y;                                                          // (the call returns the periodogram itself)
+      spp = 0.0;
+    } else {
+      const double inv_glr = p.inv_glr_factor * exp(-y / (old_psd + 1e-8) * p.inv_glr_exp_factor);   // :120-121
+      spp = 1.0 / (1.0 + inv_glr);                                                                  // :124
+      smooth = (1.0 - p.prob_smooth) * spp + p.prob_smooth * smooth;                                // :128-129
+      if (smooth > 0.99) spp = fmin(spp, 0.99);                                                     // :130-131
+      const double nper = (1.0 - spp) * y + spp * old_psd;                                          // :135-136
+      psd = (1.0 - p.fixed_smooth) * nper + p.fixed_smooth * old_psd;                               // :138-139
+      old_psd = psd;                                                                                // :142
+    }
+    if (spp_out) spp_out[(size_t)n * ldo + f] = (float)spp;
+    if (psd_out) psd_out[(size_t)n * ldo + f] = (float)psd;
+  }
+}
+
+// the `v_spp_in` branch (:145-153): the old PSD is never updated there, so it stays at its initial zeros
+__global__ void spp_given_kernel(const float* __restrict__ per, const float* __restrict__ spp_in, int64_t n, double fixed_smooth,
+                                 float* __restrict__ psd_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double nper = (double)__fmul_rn(__fsub_rn(1.f, spp_in[i]), per[i]);      // float32 product (float32 operands), then float64
+  psd_out[i] = (float)((1.0 - fixed_smooth) * nper);
+}
+
+}  // namespace
+
+extern "C" int vaenmf_spp_estimate(const float* per, int32_t ld, int32_t n_utt, const int32_t* frame_offsets, int32_t F,
+                                   double fixed_smooth, double prob_smooth, double prior, double snr_opt_db,
+                                   int32_t num_frames_init, float* spp_out, float* psd_out, int32_t ldo, void* stream) {
+  VN_REQUIRE(per && frame_offsets && n_utt > 0 && F > 0 && ld >= F && ldo >= F && (spp_out || psd_out), "vaenmf_spp_estimate: bad arguments");
+  VN_REQUIRE(prior > 0.0 && prior < 1.0 && num_frames_init >= 0, "vaenmf_spp_estimate: bad prior / num_frames_init");
+  const double snr_lin = pow(10.0, snr_opt_db / 10.0);                                              // :76
+  SppParams p{fixed_smooth, prob_smooth, (1.0 - prior) / prior * (1.0 + snr_lin), snr_lin / (1.0 + snr_lin), num_frames_init};   // :85-86
+  hipLaunchKernelGGL(spp_kernel, dim3((F + 63) / 64, n_utt), dim3(64), 0, (hipStream_t)stream, per, ld, frame_offsets, F, p, spp_out,
+                     psd_out, ldo);
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vaenmf_spp_noise_given(const float* per, const float* spp_in, int64_t n, double fixed_smooth, float* psd_out, void* stream) {
+  VN_REQUIRE(per && spp_in && psd_out && n > 0, "vaenmf_spp_noise_given: bad arguments");
+  hipLaunchKernelGGL(spp_given_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, per, spp_in, n, fixed_smooth, psd_out);
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -48,6 +48,8 @@ SIGNATURES = {
     "vaenmf_lorenz_labels": (_I, [_P, _I, _P, _I, _I, _I, _F, _F, _F, _P, _I, _P, _P, _I64, _P]),
     "vaenmf_wiener_mask": (_I, [_P, _P, _I64, _F, _P, _P]),
     "vaenmf_apply_mask": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "vaenmf_spp_estimate": (_I, [_P, _I, _I, _P, _I, _D, _D, _D, _D, _I, _P, _P, _I, _P]),
+    "vaenmf_spp_noise_given": (_I, [_P, _P, _I64, _D, _P, _P]),
     "vaenmf_gram3_batch": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "vaenmf_profile_enable": (_I, [_P, _I]),
     "vaenmf_profile_read": (_I, [_P, _P, _P]),

@@ -213,6 +213,22 @@ int vaenmf_wiener_mask(const float* S, const float* N, int64_t n, float eps, flo
 int vaenmf_apply_mask(const float* X, const float* mask, int32_t ldm, int32_t NT, int32_t F,
                       int32_t Fs, float* S_hat, void* stream);
 
+/* SPP-based speech-presence / noise-PSD estimator -- replaces SPPNoiseEstimator.update
+ * driven frame by frame (python/models/spp_estimation.py:17-160; timo_mask_estimation
+ * :163-183 is spp_out, the noise PSD the first return value).  per DEV float [NT][ld]
+ * noisy periodogram |Y|^2, frame_offsets DEV int32 [n_utt+1]; the recursion runs in
+ * float64 per (utterance, bin) and restarts at every utterance.  spp_out / psd_out DEV
+ * float [NT][ldo], either may be null.  Defaults of the reference: fixed_smooth 0.8,
+ * prob_smooth 0.9, prior 0.5, snr_opt_db 15, num_frames_init 10 (:10-14).
+ * vaenmf_spp_noise_given: the v_spp_in branch (:145-153, timo_noise_estimation
+ * :218-235), elementwise over n entries. */
+int vaenmf_spp_estimate(const float* per, int32_t ld, int32_t n_utt, const int32_t* frame_offsets,
+                        int32_t F, double fixed_smooth, double prob_smooth, double prior,
+                        double snr_opt_db, int32_t num_frames_init, float* spp_out,
+                        float* psd_out, int32_t ldo, void* stream);
+int vaenmf_spp_noise_given(const float* per, const float* spp_in, int64_t n, double fixed_smooth,
+                           float* psd_out, void* stream);
+
 /* SI-SDR sufficient statistics -- python/metrics.py:12-60: per utterance the Gram
  * matrix of (s_hat, s, n) in float64: out DEV [n_utt][6] =
  * {<sh,sh>, <sh,s>, <sh,n>, <s,s>, <s,n>, <n,n>}; sample_offsets DEV int64 [n_utt+1]. */

@@ -612,3 +612,55 @@ def ideal_wiener_mask(speech_tf, noise_tf, eps=1e-8):
     sp = np.power(abs(speech_tf), 2)
     npow = np.power(abs(noise_tf), 2)
     return sp / (sp + npow + eps)
+
+
+# ----------------------------------------------------------------------------
+# SPP-based speech-presence / noise-PSD estimator (python/models/spp_estimation.py)
+# ----------------------------------------------------------------------------
+def spp_recursion(per, fixed_smooth=0.8, prob_smooth=0.9, prior=0.5, snr_opt_db=15, num_frames_init=10):
+    """SPPNoiseEstimator.update applied frame by frame (spp_estimation.py:92-143), all bins at once.
+    per (frames, bins) -> (noise_psd, spp) float64 (frames, bins)."""
+    per = np.asarray(per)
+    nfr, nb = per.shape
+    snr = 10.0 ** (snr_opt_db / 10.0)                                    # :76
+    k_glr = (1 - prior) / prior * (1.0 + snr)                            # :85
+    k_exp = snr / (1.0 + snr)                                            # :86
+    old = np.zeros(nb)
+    smooth = np.zeros(nb)
+    psd_out = np.zeros((nfr, nb))
+    spp_out = np.zeros((nfr, nb))
+    for i in range(nfr):
+        y = per[i]
+        if i < num_frames_init:                                          # :105-117: running mean; returns the periodogram
+            old = old + y / num_frames_init
+            psd_out[i] = y
+            continue
+        inv_glr = k_glr * np.exp(-y / (old + 1e-8) * k_exp)              # :120-121
+        spp = 1.0 / (1.0 + inv_glr)                                      # :124
+        smooth = (1 - prob_smooth) * spp + prob_smooth * smooth          # :128-129
+        stuck = smooth > 0.99
+        spp[stuck] = np.minimum(spp[stuck], 0.99)                        # :130-131
+        nper = (1.0 - spp) * y + spp * old                               # :135-136
+        old = (1.0 - fixed_smooth) * nper + fixed_smooth * old           # :138-142
+        psd_out[i] = old
+        spp_out[i] = spp
+    return psd_out, spp_out
+
+
+def timo_mask_estimation(spectrogram):
+    """spp_estimation.py:163-183: (bins, frames) power spectrogram -> SPP mask, same shape and dtype."""
+    return spp_recursion(np.asarray(spectrogram).T)[1].T.astype(np.asarray(spectrogram).dtype)
+
+
+def timo_vad_estimation(spectrogram):
+    """spp_estimation.py:185-214."""
+    s = np.asarray(spectrogram).sum(axis=0)
+    return spp_recursion(s[:, None])[1][:, 0].astype(s.dtype)
+
+
+def timo_noise_estimation(spectrogram, mask, fixed_smooth=0.8):
+    """spp_estimation.py:218-235: the v_spp_in branch of update (:145-153) returns before the old PSD is stored,
+    so the old PSD is zero throughout."""
+    sp = np.asarray(spectrogram)
+    nper = (np.float32(1.0) - np.asarray(mask, np.float32)) * sp.astype(np.float32)     # float32 product (:147), then float64
+    return ((1.0 - fixed_smooth) * nper.astype(np.float64)).astype(sp.dtype)

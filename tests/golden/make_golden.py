@@ -323,6 +323,26 @@ def labels_case():
     np.savez_compressed(os.path.join(HERE, "labels_f257.npz"), **out)
 
 
+def spp_case():
+    """python/models/spp_estimation.py:163-235 on the noisy power spectrogram of a seeded synthetic mixture
+    (float32 |X|^2 as scripts/evaluate_M2_ibm.py:137-138 builds it).  Only outputs are stored; the input
+    is regenerated from the seed by the test."""
+    from python.models import spp_estimation as ref_spp
+    out = {}
+    for u, (seed, T) in enumerate(((3, 12000), (5, 9000))):
+        x = orc.synth_utterance(seed, n_samples=T)[2]
+        X = orc.stft(x, fs=16000, wlen_sec=32e-3, hop_percent=0.25)
+        P = np.power(np.abs(X), 2)                      # (F, N) float32
+        assert P.dtype == np.float32
+        m = ref_spp.timo_mask_estimation(P)
+        out["P%d" % u] = P
+        out["mask%d" % u] = m
+        out["vad%d" % u] = ref_spp.timo_vad_estimation(P)
+        out["psd%d" % u] = ref_spp.timo_noise_estimation(P, m)
+        print("spp utt", u, P.shape, "mask>0.5:", (m > 0.5).mean(), "vad mean", out["vad%d" % u].mean())
+    np.savez_compressed(os.path.join(HERE, "spp_f257.npz"), **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -332,6 +352,7 @@ if __name__ == "__main__":
     quirk_case()
     mlp_case()
     labels_case()
+    spp_case()
     metrics_case()
     # real decoder dims (L=32, H=[128,128]) so the HIP path can run the same cases
     run_case("m1_f65", "M1", F=65, N=16, K=4, dims_h=[128, 128], L=32, niter=3, counts=(10, 6, 25, 8))

@@ -554,3 +554,28 @@ def test_mask_baseline_against_oracle():
         assert nrm_err(s_hat[o:o + c], s_ref) < 2e-5
         o += c
         n0 += N
+
+
+def test_spp_estimator_against_reference():
+    """vaenmf.spp_estimation (csrc/labels.hip) against the reference's outputs (tests/golden/spp_f257.npz):
+    soft SPP within 2e-6 (float64 recursion with the device's exp, stored as float32), the hard labels
+    `mask > 0.5` of scripts/evaluate_M2_ibm.py:139 identical, the mask-driven noise PSD exact."""
+    need_gpu()
+    from vaenmf import spp_estimation as spp
+    z = np.load(os.path.join(GOLDEN, "spp_f257.npz"))
+    for u in (0, 1):
+        P = z["P%d" % u]
+        m = spp.timo_mask_estimation(P)
+        assert m.shape == P.shape and m.dtype == P.dtype
+        assert np.max(np.abs(m - z["mask%d" % u])) < 2e-6
+        assert np.array_equal(m > 0.5, z["mask%d" % u] > 0.5)
+        assert np.max(np.abs(spp.timo_vad_estimation(P) - z["vad%d" % u])) < 2e-6
+        assert np.array_equal(spp.timo_noise_estimation(P, z["mask%d" % u]), z["psd%d" % u])
+    # batch entry: both utterances in one launch, state restarted per utterance
+    per = torch.from_numpy(np.concatenate([np.ascontiguousarray(z["P%d" % u].T) for u in (0, 1)])).cuda()
+    s, psd = spp.spp_batch(per, [z["P0"].shape[1], z["P1"].shape[1]], 257, want_psd=True)
+    s, psd = s.cpu().numpy(), psd.cpu().numpy()
+    n0 = z["P0"].shape[1]
+    assert np.max(np.abs(s[:n0].T - z["mask0"])) < 2e-6 and np.max(np.abs(s[n0:].T - z["mask1"])) < 2e-6
+    ref_psd = orc.spp_recursion(z["P1"].T)[0]
+    assert np.max(np.abs(psd[n0:] - ref_psd) / (np.abs(ref_psd) + 1e-12)) < 1e-6

@@ -164,6 +164,8 @@ def test_dropin_import_paths():
         st = importlib.import_module("python.processing.stft")
         me = importlib.import_module("python.metrics")
         tg = importlib.import_module("python.processing.target")
+        sp = importlib.import_module("python.models.spp_estimation")
+        assert sp.timo_mask_estimation and sp.timo_vad_estimation and sp.timo_noise_estimation
         assert mc.MCEM_M1.__name__ == "MCEM_M1" and md.VariationalAutoencoder and st.stft and me.energy_ratios
         assert mc.MCEM_M2_noNMF and tg.clean_speech_IBM and tg.clean_speech_VAD and tg.noise_robust_clean_speech_IBM
     finally:

@@ -149,3 +149,13 @@ def test_label_front_ends_against_reference():
     for n in (1, 7, 8, 9, 127, 128, 129, 257, 1000, 24415):
         a = (g.random(n) ** 4 * 1000).astype(np.float32)
         assert orc.pairwise_sum_f32(a) == np.sum(a), n
+
+
+def test_spp_estimator_against_reference():
+    """python/models/spp_estimation.py:163-235 restated (all bins per frame at once) against the reference's outputs."""
+    z = np.load(os.path.join(GOLDEN, "spp_f257.npz"))
+    for u in (0, 1):
+        P = z["P%d" % u]
+        assert np.array_equal(orc.timo_mask_estimation(P), z["mask%d" % u])
+        assert np.array_equal(orc.timo_vad_estimation(P), z["vad%d" % u])
+        assert np.array_equal(orc.timo_noise_estimation(P, z["mask%d" % u]), z["psd%d" % u])
