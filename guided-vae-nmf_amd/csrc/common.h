@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include "../../include/vaenmf.h"
 
@@ -60,6 +61,12 @@ struct vaenmf_plan {
   float* normW;              // [n_utt][Kp]
   float* wpart;              // [n_utt][8 chunks][Fs][2 Kp] partial W-update sums
   double* cost_frames;       // [NT] (fused driver)
+  // sample-variance store (vaenmf_sample_store): the MH chain keeps the decoded variances of its samples here
+  bool store_on;
+  void* VsS;                 // [NT][store_Rs][Fs], float (bf16x3 mode) or bf16 (bf16 mode)
+  int32_t* src;              // [NT][store_Rs]
+  size_t VsS_cap, src_cap;   // allocated bytes / elements
+  int store_R, store_Rs;     // samples / slots per frame of the last chain that filled the store (0: empty)
   int n_sms;
   // optional per-kernel timing with HIP events on the launch stream (vaenmf_profile_*)
   bool prof_on;

@@ -341,6 +341,9 @@ struct ChainArgs {
   const float *X2, *W, *Ht, *g, *B1;
   const float* Vb;           // external noise variance [NT][Fs] (the *_noNMF variants, mcem.py:493-760) or null: Vb = W H
   float *Z, *Zs, *acc_out;
+  void* VsS;                 // sample-variance store [NT][Rs][Fs] (float in bf16x3 mode, bf16 in bf16 mode) or null
+  int32_t* src;              // [NT][Rs]: slot of VsS that holds the variances of sample r
+  int Rs;                    // slots per frame: nsamples + 1
   const int32_t *tile_utt, *tile_n0, *tile_cnt, *frame_off;
   const uint64_t* utt_seed;
   const float *eps, *u;      // replay buffers or null
@@ -357,7 +360,7 @@ struct ChainX {
   double epart[2][8][TEAM_COLS];
 };
 
-template <int NW, int NTEAM, int MT, bool SPLIT, bool W3LDS>
+template <int NW, int NTEAM, int MT, bool SPLIT, bool W3LDS, bool STORE>
 __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainArgs a) {
   constexpr int MAXT = MT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -450,6 +453,20 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
 #pragma unroll
     for (int t = 0; t < 4; ++t) { z[fg][t] = lo[t]; z[fg][4 + t] = hi[t]; }
   }
+  // ---- sample-variance store (STORE): the decoded variances Vs = exp(decoder(Z')) of every post-burn-in
+  // proposal go to HBM (slot r of the frame for step burnin + r) so that the M-step streams them instead of
+  // decoding the samples again; slot R holds the state the chain is in when the burn-in ends (one extra
+  // evaluation pass; the initial state itself when there is no burn-in).  src[frame][r] names the slot of the
+  // state the chain is in after post-burn-in step r (mcem.py:429-437).
+  // The rows are float in bf16x3 mode and bf16 in bf16 mode (half the HBM traffic; the decoder's own bf16 products
+  // already carry errors of that size, and each stored value enters the M-step inside a sum over the samples).
+  using store_t = typename std::conditional<SPLIT, float, __bf16>::type;
+  store_t* vsrow[2] = {nullptr, nullptr};
+  int cur_src[2] = {a.nsamples, a.nsamples};
+  if (STORE) {
+#pragma unroll
+    for (int fg = 0; fg < 2; ++fg) vsrow[fg] = fvalid[fg] ? reinterpret_cast<store_t*>(a.VsS) + (size_t)nrow[fg] * a.Rs * a.Fs : nullptr;
+  }
   // ---- noise streams: thread of the team <-> (frame of the team, latent quad); 256 streams
   const int sid = threadIdx.x - d.team * NW * 64, sfr = sid >> 3, squad = sid & 7;
   const bool srng = sid < TEAM_COLS * 8;
@@ -469,6 +486,9 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
         const size_t row = (size_t)step * a.NT + n0 + sfr;
         e = *reinterpret_cast<const f32x4*>(a.eps + row * LAT + 4 * squad);
         if (squad == 0) uu = a.u[row];
+        // retire the replay loads here: otherwise the compiler waits for vmcnt(0) where the two generator paths
+        // join, and in the on-device path that wait drains the variance stores of the previous step
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), gfx9 encoding
       }
     }
     *reinterpret_cast<f32x4*>(&L.eps[sfr][4 * squad]) = e;
@@ -481,7 +501,13 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
   // E(z) = sum_f [log Vx + X2/Vx] per frame (fp64 accumulation: the reference sums the
   // per-bin DIFFERENCES of two states, mcem.py:415-416; summing each state separately
   // needs the extra bits to keep the same absolute accuracy).
-  auto energy = [&](const float (&zz)[2][8], double (&E)[2], int next_step) {
+  // next_step: the MH step whose noise is drawn during this evaluation (>= S: none); slot: store slot or -1
+  auto energy = [&](const float (&zz)[2][8], double (&E)[2], int next_step, int slot) {
+    store_t* vdst[2] = {nullptr, nullptr};
+    if (STORE) {
+#pragma unroll
+      for (int fg = 0; fg < 2; ++fg) vdst[fg] = (slot >= 0 && vsrow[fg]) ? vsrow[fg] + (size_t)slot * a.Fs : nullptr;
+    }
     bf16x8 zhi[2], zlo[2];
     split8<SPLIT>(zz[0], zhi[0], zlo[0]);
     split8<SPLIT>(zz[1], zhi[1], zlo[1]);
@@ -497,13 +523,20 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
             // share one product, one log and one reciprocal (variances outside 1e-19..1e19 have no fp32 square
             // in the M-step either)
             float pl = 0.f, px = 0.f;                       // sum log2 Vx, sum X2 / Vx
+            f32x4 ev;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ev[t] = fast_exp(acc[t]);
 #pragma unroll
             for (int t = 0; t < 4; t += 2) {
-              const float v0 = gn[fg] * fast_exp(acc[t]) + vb[i][fg][t];
-              const float v1 = gn[fg] * fast_exp(acc[t + 1]) + vb[i][fg][t + 1];
+              const float v0 = gn[fg] * ev[t] + vb[i][fg][t];
+              const float v1 = gn[fg] * ev[t + 1] + vb[i][fg][t + 1];
               const float pp = v0 * v1;
               pl += fast_log2(pp);
               px += (x2[i][fg][t] * v1 + x2[i][fg][t + 1] * v0) * fast_rcp(pp);
+            }
+            if (STORE && vdst[fg]) {
+              if (SPLIT) *reinterpret_cast<f32x4*>(vdst[fg] + 16 * (w + NW * i) + 4 * q) = ev;
+              else *reinterpret_cast<bf16x4*>(vdst[fg] + 16 * (w + NW * i) + 4 * q) = bf16x4{(__bf16)ev[0], (__bf16)ev[1], (__bf16)ev[2], (__bf16)ev[3]};
             }
             e[fg] += (double)(pl * LN2_F + px);
           }
@@ -516,6 +549,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
         const float vx = gn[fg] * vs + vbn[fg];
         const float term = fast_log(vx) + x2n[fg] * fast_rcp(vx);
         e[fg] += (w == 0 && q == 0) ? (double)term : 0.0;        // counted once per frame
+        if (STORE && vdst[fg] && w == 0 && q == 0) vdst[fg][dw.F - 1] = (store_t)vs;
       }
     }
     const int par = ecount & 1;
@@ -536,17 +570,25 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
   };
 
   __syncthreads();                                    // staged weights and biases
+  // retire the prologue's loads here: a counted vmcnt wait for them placed inside the loop would, on every
+  // later iteration, wait for the previous step's stores instead (vmcnt counts loads and stores in order)
+  __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0), gfx9 encoding
   double Ecur[2] = {0.0, 0.0};
-  // m = -1 evaluates the initial state, Vs_t = decoder(Z_t) (mcem.py:392-400); m >= 0 are the MH steps
-  for (int m = -1; m < S; ++m) {
+  // m = -1 evaluates the initial state, Vs_t = decoder(Z_t) (mcem.py:392-400); m >= 0 are the MH steps.
+  // With the store on and a burn-in, one more pass after the burn-in re-evaluates the state the chain is in
+  // (no noise drawn, nothing decided) so that its variances are on record in slot R.
+  const bool reeval = STORE && a.burnin > 0;
+  for (int it = -1; it < S + (reeval ? 1 : 0); ++it) {
+    const bool re = reeval && it == a.burnin;
+    const int m = (reeval && it > a.burnin) ? it - 1 : it;
     // ---- proposal  Z' = Z + sqrt(var) * randn   (mcem.py:407)
     float zp[2][8];
     float e8[2][8];
-    const float sd = m < 0 ? 0.f : a.sd;
+    const float sd = (m < 0 || re) ? 0.f : a.sd;
 #pragma unroll
     for (int fg = 0; fg < 2; ++fg) {
       f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
-      if (m >= 0) {
+      if (m >= 0 && !re) {
         e0 = *reinterpret_cast<const f32x4*>(&L.eps[16 * fg + c][4 * q]);
         e1 = *reinterpret_cast<const f32x4*>(&L.eps[16 * fg + c][16 + 4 * q]);
       }
@@ -557,9 +599,11 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
         zp[fg][4 + t] = z[fg][4 + t] + sd * e1[t];
       }
     }
-    const float uu0 = m >= 0 ? L.u[c] : 1.f, uu1 = m >= 0 ? L.u[16 + c] : 1.f;
+    const float uu0 = (m >= 0 && !re) ? L.u[c] : 1.f, uu1 = (m >= 0 && !re) ? L.u[16 + c] : 1.f;
     double Ep[2];
-    energy(zp, Ep, m + 1);                            // mcem.py:410-412 (draws the next step's noise inside)
+    const int slot = !STORE ? -1 : (re ? a.nsamples : (m >= a.burnin ? m - a.burnin : ((m < 0 && a.burnin == 0) ? a.nsamples : -1)));
+    energy(zp, Ep, re ? S : m + 1, slot);             // mcem.py:410-412 (draws the next step's noise inside)
+    if (re) continue;                                 // (the state, its energy and the pending noise are untouched)
 #pragma unroll
     for (int fg = 0; fg < 2; ++fg) {
       float pr = 0.f;                                 // .5*sum(Z^2 - Z'^2)  (mcem.py:417)
@@ -577,7 +621,9 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
 #pragma unroll
         for (int j = 0; j < 8; ++j) z[fg][j] = z[fg][j] + sd * e8[fg][j];
         Ecur[fg] = Ep[fg];
+        if (STORE && m >= a.burnin) cur_src[fg] = m - a.burnin;
       }
+      if (STORE && m >= a.burnin && w == 0 && q == 0 && fvalid[fg]) a.src[(size_t)nrow[fg] * a.Rs + (m - a.burnin)] = cur_src[fg];
       if (m >= a.burnin && w == 0 && fvalid[fg]) {    // mcem.py:435-437
         float* dst = a.Zs + ((size_t)nrow[fg] * a.Rcap + (m - a.burnin)) * LAT;
         *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{z[fg][0], z[fg][1], z[fg][2], z[fg][3]};
@@ -1226,20 +1272,24 @@ void lds_plan(int NT3, size_t extra_per_team, int* w3_off, size_t* total) {
   else { *w3_off = -1; *total = base; }
 }
 
-template <int NW, int NTEAM, int MT, bool SPLIT>
-int launch_chain(ChainArgs a, int n_tiles, hipStream_t st) {
+template <int NW, int NTEAM, int MT, bool SPLIT, bool STORE>
+int launch_chain_s(ChainArgs a, int n_tiles, hipStream_t st) {
   size_t lds;
   lds_plan<NTEAM, SPLIT>(a.dw.NT3, sizeof(ChainX), &a.w3_lds_off, &lds);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, NTEAM, MT, SPLIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, NTEAM, MT, SPLIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, NTEAM, MT, SPLIT, true, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, NTEAM, MT, SPLIT, false, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
     attr_done = true;
   }
   const dim3 blk(NW * NTEAM * 64);
-  if (a.w3_lds_off >= 0) hipLaunchKernelGGL((mh_chain_kernel<NW, NTEAM, MT, SPLIT, true>), dim3(n_tiles), blk, lds, st, a);
-  else                   hipLaunchKernelGGL((mh_chain_kernel<NW, NTEAM, MT, SPLIT, false>), dim3(n_tiles), blk, lds, st, a);
+  if (a.w3_lds_off >= 0) hipLaunchKernelGGL((mh_chain_kernel<NW, NTEAM, MT, SPLIT, true, STORE>), dim3(n_tiles), blk, lds, st, a);
+  else                   hipLaunchKernelGGL((mh_chain_kernel<NW, NTEAM, MT, SPLIT, false, STORE>), dim3(n_tiles), blk, lds, st, a);
   return 0;
+}
+template <int NW, int NTEAM, int MT, bool SPLIT>
+int launch_chain(const ChainArgs& a, int n_tiles, hipStream_t st) {
+  return a.VsS ? launch_chain_s<NW, NTEAM, MT, SPLIT, true>(a, n_tiles, st) : launch_chain_s<NW, NTEAM, MT, SPLIT, false>(a, n_tiles, st);
 }
 
 template <int NW, int NTEAM, int MT, bool SPLIT, int MODE, int KP>
@@ -1323,6 +1373,25 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
   a.rng_mode = rng->mode; a.call = rng->call; a.sd = sqrtf(var_rw); a.update_Z = update_Z;
   hipStream_t st = (hipStream_t)stream;
   const bool split = p->cfg.precision == VAENMF_PREC_BF16X3;
+  p->store_R = p->store_Rs = 0;
+  if (p->store_on) {                                    // sample-variance store: grown on demand, reused across calls
+    const int Rs = nsamples + 1;
+    const size_t esz = split ? sizeof(float) : sizeof(__bf16);
+    const size_t need_v = (size_t)p->NT * Rs * p->Fs * esz, need_s = (size_t)p->NT * Rs;
+    if (need_v > p->VsS_cap) {
+      if (p->VsS) VN_CHECK_HIP(hipFree(p->VsS));
+      p->VsS = nullptr; p->VsS_cap = 0;
+      VN_CHECK_HIP(hipMalloc(&p->VsS, need_v));
+      p->VsS_cap = need_v;
+    }
+    if (need_s > p->src_cap) {
+      if (p->src) VN_CHECK_HIP(hipFree(p->src));
+      p->src = nullptr; p->src_cap = 0;
+      VN_CHECK_HIP(hipMalloc(&p->src, need_s * sizeof(int32_t)));
+      p->src_cap = need_s;
+    }
+    a.VsS = p->VsS; a.src = p->src; a.Rs = Rs;
+  }
   ProfScope ps(p, VN_K_CHAIN, st);
   switch (p->geom) {
     case 0: if (split) launch_chain<4, 2, 5, true>(a, p->n_tiles, st); else launch_chain<4, 2, 5, false>(a, p->n_tiles, st); break;
@@ -1330,6 +1399,37 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
     case 4: if (split) launch_chain<8, 1, 4, true>(a, p->n_tiles, st); else launch_chain<8, 1, 4, false>(a, p->n_tiles, st); break;
     default: if (split) launch_chain<8, 1, 5, true>(a, p->n_tiles, st); else launch_chain<8, 1, 5, false>(a, p->n_tiles, st); break;
   }
+  VN_CHECK_HIP(hipGetLastError());
+  if (p->store_on) { p->store_R = nsamples; p->store_Rs = nsamples + 1; }
+  return 0;
+}
+
+extern "C" int vaenmf_sample_store(vaenmf_plan* p, int32_t enable) {
+  VN_REQUIRE(p != nullptr, "null plan");
+  p->store_on = enable != 0;
+  p->store_R = p->store_Rs = 0;
+  return 0;
+}
+
+namespace {
+template <typename ST>
+__global__ void store_gather_kernel(const ST* __restrict__ VsS, const int32_t* __restrict__ src, int NT, int R, int Rs, int Fs,
+                                    float* __restrict__ out) {
+  const int n = blockIdx.x / R, r = blockIdx.x - n * R;
+  const ST* row = VsS + ((size_t)n * Rs + src[(size_t)n * Rs + r]) * Fs;
+  for (int f = threadIdx.x; f < Fs; f += blockDim.x) out[((size_t)n * R + r) * Fs + f] = (float)row[f];
+}
+}  // namespace
+
+extern "C" int vaenmf_sample_store_gather(vaenmf_plan* p, float* Vs_out, void* stream) {
+  VN_REQUIRE(p != nullptr && p->store_R > 0, "the sample store is empty (vaenmf_sample_store(plan, 1), then vaenmf_mh_chain)");
+  VN_REQUIRE(Vs_out != nullptr, "null output");
+  if (p->cfg.precision == VAENMF_PREC_BF16X3)
+    hipLaunchKernelGGL(store_gather_kernel<float>, dim3((unsigned)(p->NT * p->store_R)), dim3(64), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float*>(p->VsS), p->src, p->NT, p->store_R, p->store_Rs, p->Fs, Vs_out);
+  else
+    hipLaunchKernelGGL(store_gather_kernel<__bf16>, dim3((unsigned)(p->NT * p->store_R)), dim3(64), 0, (hipStream_t)stream,
+                       reinterpret_cast<const __bf16*>(p->VsS), p->src, p->NT, p->store_R, p->store_Rs, p->Fs, Vs_out);
   VN_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1393,14 +1493,22 @@ extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* H
   VN_REQUIRE(nsE <= Rcap && nsWF <= Rcap, "Rcap=%d too small for nsE=%d / nsWF=%d", Rcap, nsE, nsWF);
   hipStream_t st = (hipStream_t)stream;
   vaenmf_rng rng = {VAENMF_RNG_DEVICE, 0, nullptr, nullptr};
+  // with the sample store on (vaenmf_sample_store), the chain leaves the samples' variances in HBM and the
+  // M-step / Wiener filter stream them; otherwise they decode Zs again
+  const bool stored = p->store_on;
   for (int it = 0; it < niter; ++it) {                  // EM.run, mcem.py:159-165
     rng.call = (uint32_t)it;
-    if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, 1, B1, Zs, Rcap, nsE, biE, var_rw, &rng, nullptr, stream)) return e;
-    if (int e = vaenmf_m_step(p, X2, W, Ht, g, Zs, Rcap, nsE, B1, p->cost_frames, stream)) return e;
-    if (cost) if (int e = vn_launch_cost_reduce(p, p->cost_frames, nsE, cost, niter, it, st)) return e;
+    p->store_on = stored;
+    if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, 1, B1, Zs, Rcap, nsE, biE, var_rw, &rng, nullptr, stream)) { p->store_on = stored; return e; }
+    int e = p->store_on ? vaenmf_m_step_stored(p, X2, W, Ht, g, p->cost_frames, stream)
+                        : vaenmf_m_step(p, X2, W, Ht, g, Zs, Rcap, nsE, B1, p->cost_frames, stream);
+    p->store_on = stored;
+    if (e) return e;
+    if (cost) if (int e2 = vn_launch_cost_reduce(p, p->cost_frames, nsE, cost, niter, it, st)) return e2;
   }
   rng.call = (uint32_t)niter;                           // compute_WF(sample=True), mcem.py:173
   if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, 0, B1, Zs, Rcap, nsWF, biWF, var_rw, &rng, nullptr, stream)) return e;
+  if (stored) return vaenmf_wiener_stored(p, W, Ht, g, X, S_hat, N_hat, nullptr, nullptr, stream);
   return vaenmf_wiener(p, X2, W, Ht, g, Zs, Rcap, nsWF, B1, X, S_hat, N_hat, nullptr, nullptr, stream);
 }
 

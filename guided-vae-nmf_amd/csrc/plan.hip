@@ -96,6 +96,8 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   p->Dy = 0;
   p->have_weights = false;
   p->Vb_ext = nullptr;
+  p->store_on = false; p->VsS = nullptr; p->src = nullptr; p->VsS_cap = p->src_cap = 0; p->store_R = p->store_Rs = 0;
+  if (const char* sv = getenv("VAENMF_STORE")) p->store_on = sv[0] == '1';   // dev override (A/B runs)
   p->n_utt = p->NT = p->n_tiles = 0;
   p->prof_on = false;
   p->prof_used = 0;
@@ -134,7 +136,8 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
 extern "C" void vaenmf_plan_destroy(vaenmf_plan* p) {
   if (!p) return;
   void* ptrs[] = {p->w1f, p->w2f, p->w3f, p->b1, p->b2, p->b3, p->w3n, p->w1y, p->d_frame_off, p->d_tile_utt, p->d_tile_n0,
-                  p->d_tile_cnt, p->d_frame_utt, p->d_frame_loc, p->d_utt_seed, p->A1, p->P, p->normW, p->wpart, p->cost_frames};
+                  p->d_tile_cnt, p->d_frame_utt, p->d_frame_loc, p->d_utt_seed, p->A1, p->P, p->normW, p->wpart, p->cost_frames,
+                  p->VsS, p->src};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);

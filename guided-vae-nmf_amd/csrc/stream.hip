@@ -1,0 +1,589 @@
+// M-step and Wiener filter over the sample-variance store (EM.M_step mcem.py:90-152, cost :68-70,
+// compute_WF :486-488): the variances Vs[n][r][f] of the chain's samples were written to HBM by
+// mh_chain_kernel (engine.hip, STORE), so these kernels stream them instead of running the decoder
+// again.  They are plain bandwidth kernels: one wavefront owns one frame at a time, a lane owns four
+// consecutive bins per 256-bin chunk (one 1 KiB row segment per load instruction), the samples are a
+// sequential loop, and everything a frame needs beyond its own row -- sums over bins for H, g and the
+// cost -- is a wavefront reduction (DPP / permlane, no LDS, no barrier).
+//
+//   wstats_stream   A1 = sum_r 1/Vx, P = X2 sum_r 1/Vx^2 with the pre-update W, H, g        (:107-109)
+//   hg_stream       H <- H sqrt(num/den) with the updated W (:118-121), refreshed Vb (:124-125),
+//                   g <- g sqrt(num/den) (:138-142), cost with the refreshed variances (:70, :151-152);
+//                   three passes over the frame's rows, which stay in registers when they fit one batch
+//   wf_stream       Wiener masks mean_r(g Vs/Vx), mean_r(Vb/Vx) and S_hat, N_hat            (:486-488, :175-176)
+//
+// Bins of the odd last bin and the padding (f >= Fm: F-1 when F = 16k+1) are handled as one extra
+// element that every lane computes redundantly (same address: a broadcast load).
+#include "common.h"
+
+namespace {
+
+struct StreamArgs {
+  const void* VsS;             // [NT][Rs][Fs], float or bf16 (template ST)
+  const int32_t* src;          // [NT][Rs]
+  const float *X2, *W, *normW, *Vb, *X;
+  float *Ht, *g, *A1, *P, *S_hat, *N_hat, *WFs, *WFn;
+  double* cost_frames;
+  const int32_t* frame_utt;
+  int NT, R, Rs, F, Fm, Fs, K;
+  int gains_only;              // the *_noNMF M-step (mcem.py:543-578): Vb given, only g moves
+  int store_f32;               // rows are float (bf16x3 mode) rather than bf16
+};
+
+__device__ __forceinline__ float wave_sum(float v) { return sum_rows4(sum_row16(v)); }
+
+template <int NCH, int KP, typename ST>
+struct FrameCtx {
+  const StreamArgs& a;
+  int lane;
+  bool cv[NCH];                // chunk c holds real bins for this lane
+  int f0[NCH];
+  bool has_x;                  // an extra bin F-1 beside the 4-bin chunks
+  // W of the utterance the wavefront is in, in a wave-private piece of LDS (rank <= 8; no barrier: only this
+  // wavefront touches it).  Read from global memory per frame the rows dominate the L1 traffic: a lane's 4 rows
+  // are 128 B from the next lane's, so every load instruction touches 64 cache lines -- ~3500 line accesses per
+  // frame against ~120 for the variances.
+  static constexpr bool WLDS = KP <= 8;
+  float* wl;                   // [Fs][KP]
+  int wutt;
+  __device__ FrameCtx(const StreamArgs& a_, float* wl_) : a(a_), wl(wl_) {
+    lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { f0[c] = 256 * c + 4 * lane; cv[c] = f0[c] < a.Fm; }
+    has_x = a.F != a.Fm;
+    wutt = -1;
+  }
+  __device__ __forceinline__ void set_utt(int utt) {        // wave-uniform
+    if (!WLDS || utt == wutt) return;
+    wutt = utt;
+    __builtin_amdgcn_wave_barrier();                        // earlier reads of the previous utterance's rows
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.W + (size_t)utt * a.Fs * KP);
+    for (int e = lane; e < a.Fs * KP / 4; e += 64) reinterpret_cast<f32x4*>(wl)[e] = src[e];
+    __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the rows are in LDS (gfx9 encoding)
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ float w_at(int utt, int c, int t, int k) const {
+    return WLDS ? wl[(f0[c] + t) * KP + k] : a.W[((size_t)utt * a.Fs + f0[c] + t) * KP + k];
+  }
+  __device__ __forceinline__ float wx_at(int utt, int k) const {
+    return WLDS ? wl[(a.F - 1) * KP + k] : a.W[((size_t)utt * a.Fs + a.F - 1) * KP + k];
+  }
+  // Vb = sum_k W[f,k] h[k] for this lane's bins (+ the extra bin); set_utt(utt) first
+  __device__ __forceinline__ void noise_var(int utt, const float (&h)[KP], f32x4 (&vb)[NCH], float& vbx) const {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      vb[c] = f32x4{1.f, 1.f, 1.f, 1.f};
+      if (cv[c]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float v = 0.f;
+          const float* wrow = WLDS ? wl + (f0[c] + t) * KP : a.W + ((size_t)utt * a.Fs + f0[c] + t) * KP;
+#pragma unroll
+          for (int k = 0; k < KP; k += 4) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow + k);
+            v += w4[0] * h[k] + w4[1] * h[k + 1] + w4[2] * h[k + 2] + w4[3] * h[k + 3];
+          }
+          vb[c][t] = v;
+        }
+      }
+    }
+    vbx = 1.f;
+    if (has_x) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) v += wx_at(utt, k) * h[k];
+      vbx = v;
+    }
+  }
+  __device__ __forceinline__ void ext_var(int n, f32x4 (&vb)[NCH], float& vbx) const {   // caller-given Vb (noNMF)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      vb[c] = cv[c] ? *reinterpret_cast<const f32x4*>(a.Vb + (size_t)n * a.Fs + f0[c]) : f32x4{1.f, 1.f, 1.f, 1.f};
+    vbx = has_x ? a.Vb[(size_t)n * a.Fs + a.F - 1] : 1.f;
+  }
+  __device__ __forceinline__ void load_x2(int n, f32x4 (&x2)[NCH], float& x2x) const {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      x2[c] = cv[c] ? *reinterpret_cast<const f32x4*>(a.X2 + (size_t)n * a.Fs + f0[c]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    x2x = has_x ? a.X2[(size_t)n * a.Fs + a.F - 1] : 0.f;
+  }
+  // variances of sample r of frame n (row of the store), this lane's bins; lanes without bins read a valid dummy
+  __device__ __forceinline__ void load_vs(const ST* row, f32x4 (&v)[NCH], float& vx) const {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (sizeof(ST) == 4) {
+        v[c] = *reinterpret_cast<const f32x4*>(row + (cv[c] ? f0[c] : 0));
+      } else {
+        const bf16x4 b = *reinterpret_cast<const bf16x4*>(row + (cv[c] ? f0[c] : 0));
+        v[c] = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+      }
+    }
+    vx = (float)row[has_x ? a.F - 1 : 0];
+  }
+  // write a per-bin result row (bins >= F zeroed)
+  __device__ __forceinline__ void store_row(float* dst, const f32x4 (&v)[NCH], float vx) const {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (cv[c]) *reinterpret_cast<f32x4*>(dst + f0[c]) = v[c];
+    if (a.Fm + lane < a.Fs) dst[a.Fm + lane] = (lane == 0 && has_x) ? vx : 0.f;
+  }
+};
+
+// A batch of up to RB rows of one frame in registers (this lane's bins, still packed as stored): every load of
+// the batch is issued before the first use, so a wavefront keeps RB x 0.5-1 KiB in flight -- the kernels are
+// latency-bound otherwise (86 % of the wave time in s_waitcnt with 4 loads in flight) -- and the H / g / cost
+// passes of hg_stream reuse the registers instead of reading the rows again when the frame fits one batch.
+template <int NCH, typename ST>
+struct RowBatch {
+  static constexpr int RB = (sizeof(ST) == 2 ? 32 : 16) / NCH;
+  using raw_t = typename std::conditional<sizeof(ST) == 4, f32x4, bf16x4>::type;
+  raw_t raw[RB][NCH];
+  float xr;                    // lane j: extra bin (F-1) of row j of the batch
+  int nr;
+  // rows r0 .. r0+nr-1 of the frame whose store block starts at `base`; slot map row `srow`
+  template <typename FC>
+  __device__ __forceinline__ void load(const FC& fc, const ST* base, const int32_t* srow, int r0, int R) {
+    nr = R - r0 < RB ? R - r0 : RB;
+    const int sl = fc.lane < nr ? srow[r0 + fc.lane] : srow[r0];
+    xr = fc.has_x ? (float)base[(size_t)sl * fc.a.Fs + fc.a.F - 1] : 0.f;
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+      if (r < nr) {
+        const ST* row = base + (size_t)__builtin_amdgcn_readlane(sl, r) * fc.a.Fs;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) raw[r][c] = *reinterpret_cast<const raw_t*>(row + (fc.cv[c] ? fc.f0[c] : 0));
+      }
+  }
+  __device__ __forceinline__ void get(int r, f32x4 (&v)[NCH]) const {     // r: compile-time after unrolling
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) v[c] = f32x4{(float)raw[r][c][0], (float)raw[r][c][1], (float)raw[r][c][2], (float)raw[r][c][3]};
+  }
+  // The extra bin is handled across the lanes instead of along the row loop: lane j holds it for row j, so a
+  // sum over the samples is one wavefront reduction of a per-lane term (xmask() zeroes the lanes without a row).
+  template <typename FC>
+  __device__ __forceinline__ float xmask(const FC& fc) const { return (fc.has_x && fc.lane < nr) ? 1.f : 0.f; }
+};
+
+// frames of a wavefront: a contiguous block, so consecutive frames share the utterance (W rows stay in L1)
+__device__ __forceinline__ void wave_frames(int NT, int& n_beg, int& n_end) {
+  const int wpb = blockDim.x >> 6;
+  const int gw = blockIdx.x * wpb + (threadIdx.x >> 6), nw = gridDim.x * wpb;
+  const int per = (NT + nw - 1) / nw;
+  n_beg = gw * per;
+  n_end = n_beg + per < NT ? n_beg + per : NT;
+}
+
+template <int NCH, int KP, typename ST>
+__global__ __launch_bounds__(256) void wstats_stream_kernel(const StreamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  FrameCtx<NCH, KP, ST> fc(a, wlds + (size_t)(threadIdx.x >> 6) * a.Fs * KP);
+  using RBt = RowBatch<NCH, ST>;
+  int n_beg, n_end;
+  wave_frames(a.NT, n_beg, n_end);
+  for (int n = n_beg; n < n_end; ++n) {
+    const ST* base = reinterpret_cast<const ST*>(a.VsS) + (size_t)n * a.Rs * a.Fs;
+    const int32_t* srow = a.src + (size_t)n * a.Rs;
+    RBt rb;
+    rb.load(fc, base, srow, 0, a.R);                 // (issued first: the longest latency of the frame)
+    const int utt = a.frame_utt[n];
+    fc.set_utt(utt);
+    const float gn = a.g[n];
+    float h[KP];
+#pragma unroll
+    for (int k = 0; k < KP; k += 4) {
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h[k + t] = hv[t];
+    }
+    f32x4 vb[NCH], x2[NCH], a1[NCH], a2[NCH];
+    float vbx, x2x, a1x = 0.f, a2x = 0.f;
+    fc.noise_var(utt, h, vb, vbx);
+    fc.load_x2(n, x2, x2x);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) a1[c] = a2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < a.R; r0 += RBt::RB) {
+      if (r0 > 0) rb.load(fc, base, srow, r0, a.R);
+#pragma unroll
+      for (int r = 0; r < RBt::RB; ++r)
+        if (r < rb.nr) {
+          f32x4 v[NCH];
+          rb.get(r, v);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
+              a1[c][t] += q;
+              a2[c][t] += q * q;
+            }
+        }
+      const float q = fast_rcp(gn * rb.xr + vbx) * rb.xmask(fc);
+      a1x += wave_sum(q);
+      a2x += wave_sum(q * q);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a2[c][t] *= x2[c][t];
+    fc.store_row(a.A1 + (size_t)n * a.Fs, a1, a1x);
+    fc.store_row(a.P + (size_t)n * a.Fs, a2, a2x * x2x);
+  }
+}
+
+template <int NCH, int KP, typename ST>
+__global__ __launch_bounds__(256) void hg_stream_kernel(const StreamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  FrameCtx<NCH, KP, ST> fc(a, wlds + (size_t)(threadIdx.x >> 6) * a.Fs * KP);
+  using RBt = RowBatch<NCH, ST>;
+  int n_beg, n_end;
+  wave_frames(a.NT, n_beg, n_end);
+  const bool one = a.R <= RBt::RB;                    // the frame fits one batch: its rows are read once
+  for (int n = n_beg; n < n_end; ++n) {
+    const ST* base = reinterpret_cast<const ST*>(a.VsS) + (size_t)n * a.Rs * a.Fs;
+    const int32_t* srow = a.src + (size_t)n * a.Rs;
+    RBt rb;
+    rb.load(fc, base, srow, 0, a.R);
+    const int utt = a.frame_utt[n];
+    fc.set_utt(utt);
+    const float gn = a.g[n];
+    f32x4 vb[NCH], x2[NCH];
+    float vbx, x2x;
+    fc.load_x2(n, x2, x2x);
+    if (a.gains_only) {
+      fc.ext_var(n, vb, vbx);
+    } else {
+      // ---- H update (mcem.py:118-121): W already updated and normalised; H carries the pending column norms
+      float hs[KP];
+#pragma unroll
+      for (int k = 0; k < KP; k += 4) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
+        const f32x4 nv = *reinterpret_cast<const f32x4*>(a.normW + (size_t)utt * KP + k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) hs[k + t] = hv[t] * nv[t];
+      }
+      fc.noise_var(utt, hs, vb, vbx);
+      f32x4 a1[NCH], a2[NCH];
+      float a1x = 0.f, a2x = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) a1[c] = a2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int r0 = 0; r0 < a.R; r0 += RBt::RB) {
+        if (r0 > 0) rb.load(fc, base, srow, r0, a.R);
+#pragma unroll
+        for (int r = 0; r < RBt::RB; ++r)
+          if (r < rb.nr) {
+            f32x4 v[NCH];
+            rb.get(r, v);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
+                a1[c][t] += q;
+                a2[c][t] += q * q;
+              }
+          }
+        const float q = fast_rcp(gn * rb.xr + vbx) * rb.xmask(fc);
+        a1x += wave_sum(q);
+        a2x += wave_sum(q * q);
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          a2[c][t] = fc.cv[c] ? a2[c][t] * x2[c][t] : 0.f;
+          a1[c][t] = fc.cv[c] ? a1[c][t] : 0.f;
+        }
+      const bool lead = fc.lane == 0 && fc.has_x;
+      a2x = lead ? a2x * x2x : 0.f;
+      a1x = lead ? a1x : 0.f;
+      float hn[KP];
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        float nu = 0.f, de = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+          if (fc.cv[c]) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float w = fc.w_at(utt, c, t, k);
+              nu += w * a2[c][t];
+              de += w * a1[c][t];
+            }
+          }
+        if (fc.has_x) {
+          const float w = fc.wx_at(utt, k);
+          nu += w * a2x;
+          de += w * a1x;
+        }
+        nu = wave_sum(nu);
+        de = wave_sum(de);
+        hn[k] = k < a.K ? hs[k] * __builtin_amdgcn_sqrtf(nu * fast_rcp(de)) : 0.f;       // mcem.py:121
+      }
+      if (fc.lane == 0) {
+#pragma unroll
+        for (int k = 0; k < KP; k += 4)
+          *reinterpret_cast<f32x4*>(a.Ht + (size_t)n * KP + k) = f32x4{hn[k], hn[k + 1], hn[k + 2], hn[k + 3]};
+      }
+      fc.noise_var(utt, hn, vb, vbx);                                                     // mcem.py:124-125
+    }
+    // ---- g update (mcem.py:138-142 / :564-568)
+    float nu = 0.f, de = 0.f;
+    {
+      f32x4 ng[NCH], dg[NCH];
+      float ngx = 0.f, dgx = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) ng[c] = dg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int r0 = 0; r0 < a.R; r0 += RBt::RB) {
+        if (!one) rb.load(fc, base, srow, r0, a.R);
+#pragma unroll
+        for (int r = 0; r < RBt::RB; ++r)
+          if (r < rb.nr) {
+            f32x4 v[NCH];
+            rb.get(r, v);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
+                const float vq = v[c][t] * q;
+                dg[c][t] += vq;                 // sum_r Vs / Vx
+                ng[c][t] += vq * q;             // sum_r Vs / Vx^2
+              }
+          }
+        const float q = fast_rcp(gn * rb.xr + vbx), vq = rb.xr * q * rb.xmask(fc);
+        dgx += wave_sum(vq);
+        ngx += wave_sum(vq * q);
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (fc.cv[c]) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { nu += x2[c][t] * ng[c][t]; de += dg[c][t]; }
+        }
+      if (fc.lane == 0 && fc.has_x) { nu += x2x * ngx; de += dgx; }
+      nu = wave_sum(nu);
+      de = wave_sum(de);
+    }
+    const float gnew = gn * __builtin_amdgcn_sqrtf(nu * fast_rcp(de));                     // mcem.py:142
+    if (fc.lane == 0) a.g[n] = gnew;
+    // ---- cost (mcem.py:70) with the refreshed variances (:151-152); samples two at a time:
+    // log Vx0 + log Vx1 = log(Vx0 Vx1), 1/Vx0 + 1/Vx1 = (Vx0 + Vx1)/(Vx0 Vx1)
+    f32x4 cl[NCH], cx[NCH];
+    float clx = 0.f, cxx = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) cl[c] = cx[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < a.R; r0 += RBt::RB) {
+      if (!one) rb.load(fc, base, srow, r0, a.R);
+#pragma unroll
+      for (int r = 0; r < RBt::RB; r += 2) {
+        if (r + 1 < rb.nr) {
+          f32x4 v0[NCH], v1[NCH];
+          rb.get(r, v0);
+          rb.get(r + 1, v1);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float x0 = gnew * v0[c][t] + vb[c][t], x1 = gnew * v1[c][t] + vb[c][t];
+              const float pp = x0 * x1;
+              cl[c][t] += fast_log2(pp);
+              cx[c][t] += (x0 + x1) * fast_rcp(pp);
+            }
+        } else if (r < rb.nr) {
+          f32x4 v0[NCH];
+          rb.get(r, v0);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float x0 = gnew * v0[c][t] + vb[c][t];
+              cl[c][t] += fast_log2(x0);
+              cx[c][t] += fast_rcp(x0);
+            }
+        }
+      }
+      const float xm = rb.xmask(fc), x0 = gnew * rb.xr + vbx;
+      clx += wave_sum(fast_log2(x0) * xm);
+      cxx += wave_sum(fast_rcp(x0) * xm);
+    }
+    float cs = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (fc.cv[c]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cs += cl[c][t] * LN2_F + x2[c][t] * cx[c][t];
+      }
+    if (fc.lane == 0 && fc.has_x) cs += clx * LN2_F + x2x * cxx;
+    const double cd = sum_rows4_d((double)sum_row16(cs));     // rows in fp32 (DPP), then fp64 across the 4 rows
+    if (fc.lane == 0) a.cost_frames[n] = cd;
+  }
+}
+
+template <int NCH, int KP, typename ST>
+__global__ __launch_bounds__(256) void wf_stream_kernel(const StreamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  FrameCtx<NCH, KP, ST> fc(a, wlds + (size_t)(threadIdx.x >> 6) * a.Fs * KP);
+  using RBt = RowBatch<NCH, ST>;
+  int n_beg, n_end;
+  wave_frames(a.NT, n_beg, n_end);
+  const float invR = 1.0f / (float)a.R;
+  for (int n = n_beg; n < n_end; ++n) {
+    const ST* base = reinterpret_cast<const ST*>(a.VsS) + (size_t)n * a.Rs * a.Fs;
+    const int32_t* srow = a.src + (size_t)n * a.Rs;
+    RBt rb;
+    rb.load(fc, base, srow, 0, a.R);
+    const int utt = a.frame_utt[n];
+    fc.set_utt(utt);
+    const float gn = a.g[n];
+    f32x4 vb[NCH];
+    float vbx;
+    if (a.Vb) {
+      fc.ext_var(n, vb, vbx);
+    } else {
+      float h[KP];
+#pragma unroll
+      for (int k = 0; k < KP; k += 4) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h[k + t] = hv[t];
+      }
+      fc.noise_var(utt, h, vb, vbx);
+    }
+    f32x4 ws[NCH], wn[NCH];
+    float wsx = 0.f, wnx = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) ws[c] = wn[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < a.R; r0 += RBt::RB) {
+      if (r0 > 0) rb.load(fc, base, srow, r0, a.R);
+#pragma unroll
+      for (int r = 0; r < RBt::RB; ++r)
+        if (r < rb.nr) {
+          f32x4 v[NCH];
+          rb.get(r, v);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float sc = gn * v[c][t];
+              const float q = fast_rcp(sc + vb[c][t]);
+              ws[c][t] += sc * q;                 // g Vs / Vx
+              wn[c][t] += vb[c][t] * q;           // Vb / Vx
+            }
+        }
+      const float sc = gn * rb.xr, q = fast_rcp(sc + vbx) * rb.xmask(fc);
+      wsx += wave_sum(sc * q);
+      wnx += wave_sum(vbx * q);
+    }
+    // S_hat = WFs X, N_hat = WFn X (mcem.py:175-176); bins >= F zeroed
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (fc.cv[c]) {
+        const size_t o = (size_t)n * a.Fs + fc.f0[c];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float ms = ws[c][t] * invR, mn = wn[c][t] * invR;
+          const float xr = a.X[2 * (o + t)], xi = a.X[2 * (o + t) + 1];
+          a.S_hat[2 * (o + t)] = ms * xr;  a.S_hat[2 * (o + t) + 1] = ms * xi;
+          a.N_hat[2 * (o + t)] = mn * xr;  a.N_hat[2 * (o + t) + 1] = mn * xi;
+          if (a.WFs) a.WFs[o + t] = ms;
+          if (a.WFn) a.WFn[o + t] = mn;
+        }
+      }
+    if (a.Fm + fc.lane < a.Fs) {
+      const size_t o = (size_t)n * a.Fs + a.Fm + fc.lane;
+      const bool lead = fc.lane == 0 && fc.has_x;
+      const float ms = lead ? wsx * invR : 0.f, mn = lead ? wnx * invR : 0.f;
+      const float xr = a.X[2 * o], xi = a.X[2 * o + 1];
+      a.S_hat[2 * o] = ms * xr;  a.S_hat[2 * o + 1] = ms * xi;
+      a.N_hat[2 * o] = mn * xr;  a.N_hat[2 * o + 1] = mn * xi;
+      if (a.WFs) a.WFs[o] = ms;
+      if (a.WFn) a.WFn[o] = mn;
+    }
+  }
+}
+
+StreamArgs base_args(const vaenmf_plan* p) {
+  StreamArgs a = {};
+  a.VsS = p->VsS; a.src = p->src; a.frame_utt = p->d_frame_utt; a.Vb = p->Vb_ext;
+  a.store_f32 = p->cfg.precision == VAENMF_PREC_BF16X3;
+  a.NT = p->NT; a.R = p->store_R; a.Rs = p->store_Rs; a.F = p->cfg.F; a.Fm = p->Fm; a.Fs = p->Fs; a.K = p->cfg.K;
+  return a;
+}
+
+enum { SK_WSTATS, SK_HG, SK_WF };
+
+template <int KIND, int NCH, int KP, typename ST>
+void launch_st(const StreamArgs& a, int grid, hipStream_t st) {
+  const size_t lds = KP <= 8 ? (size_t)4 * a.Fs * KP * sizeof(float) : 0;     // one W[utt] per wavefront
+  if (KIND == SK_WSTATS) hipLaunchKernelGGL((wstats_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
+  else if (KIND == SK_HG) hipLaunchKernelGGL((hg_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((wf_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
+}
+template <int KIND, int NCH, int KP>
+void launch_one(const StreamArgs& a, int grid, hipStream_t st) {
+  if (a.store_f32) launch_st<KIND, NCH, KP, float>(a, grid, st);
+  else launch_st<KIND, NCH, KP, __bf16>(a, grid, st);
+}
+template <int KIND, int NCH>
+void launch_kp(const StreamArgs& a, int Kp, int grid, hipStream_t st) {
+  switch (Kp) {
+    case 8: launch_one<KIND, NCH, 8>(a, grid, st); break;
+    case 16: launch_one<KIND, NCH, 16>(a, grid, st); break;
+    default: launch_one<KIND, NCH, 32>(a, grid, st); break;
+  }
+}
+template <int KIND>
+int launch_stream(const vaenmf_plan* p, const StreamArgs& a, hipStream_t st) {
+  const int nch = (p->Fm + 255) / 256;
+  // enough wavefronts in flight to cover the HBM latency: 4 per SIMD, blocks of 4 wavefronts
+  int mult = 8;      // (finer than the resident wave count: the last round of blocks stays balanced)
+  if (const char* e = getenv("VAENMF_SGRID")) mult = atoi(e) > 0 ? atoi(e) : 8;      // dev override (A/B runs)
+  int grid = p->n_sms * mult;
+  if (grid * 4 > p->NT) grid = (p->NT + 3) / 4;
+  if (nch <= 1) launch_kp<KIND, 1>(a, p->Kp, grid, st);
+  else if (nch == 2) launch_kp<KIND, 2>(a, p->Kp, grid, st);
+  else launch_kp<KIND, 3>(a, p->Kp, grid, st);
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int check_store(const vaenmf_plan* p) {
+  VN_REQUIRE(p != nullptr && p->have_weights && p->NT > 0, "plan not ready");
+  VN_REQUIRE(p->store_R > 0, "the sample store is empty: vaenmf_sample_store(plan, 1), then vaenmf_mh_chain");
+  VN_REQUIRE(p->Fm <= 768, "F = %d: the streaming kernels cover up to 769 bins", p->cfg.F);
+  return 0;
+}
+
+}  // namespace
+
+// aux.hip
+int vn_launch_w_update(const vaenmf_plan* p, float* W, const float* Ht, hipStream_t st);
+
+extern "C" int vaenmf_m_step_stored(vaenmf_plan* p, const float* X2, float* W, float* Ht, float* g, double* cost_frames,
+                                    void* stream) {
+  if (int e = check_store(p)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  StreamArgs a = base_args(p);
+  a.X2 = X2; a.W = W; a.Ht = Ht; a.g = g; a.A1 = p->A1; a.P = p->P; a.normW = p->normW;
+  a.cost_frames = cost_frames ? cost_frames : p->cost_frames;
+  if (p->Vb_ext) {                                      // noNMF: only the gains move (mcem.py:543-578)
+    a.gains_only = 1;
+    ProfScope ps(p, VN_K_HG, st);
+    return launch_stream<SK_HG>(p, a, st);
+  }
+  { ProfScope ps(p, VN_K_WSTATS, st); if (int e = launch_stream<SK_WSTATS>(p, a, st)) return e; }
+  { ProfScope ps(p, VN_K_WUPDATE, st); if (int e = vn_launch_w_update(p, W, Ht, st)) return e; }
+  { ProfScope ps(p, VN_K_HG, st); if (int e = launch_stream<SK_HG>(p, a, st)) return e; }
+  return 0;
+}
+
+extern "C" int vaenmf_wiener_stored(vaenmf_plan* p, const float* W, const float* Ht, const float* g, const float* X,
+                                    float* S_hat, float* N_hat, float* WFs, float* WFn, void* stream) {
+  if (int e = check_store(p)) return e;
+  VN_REQUIRE(X && S_hat && N_hat, "vaenmf_wiener_stored: null spectrogram / outputs");
+  StreamArgs a = base_args(p);
+  a.W = W; a.Ht = const_cast<float*>(Ht); a.g = const_cast<float*>(g); a.X = X;
+  a.S_hat = S_hat; a.N_hat = N_hat; a.WFs = WFs; a.WFn = WFn;
+  ProfScope ps(p, VN_K_WF, (hipStream_t)stream);
+  return launch_stream<SK_WF>(p, a, (hipStream_t)stream);
+}

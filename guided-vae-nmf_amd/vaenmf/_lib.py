@@ -34,6 +34,10 @@ SIGNATURES = {
     "vaenmf_set_noise_psd": (_I, [_P, _P]),
     "vaenmf_layer1_bias": (_I, [_P, _P, _I, _P, _P]),
     "vaenmf_mh_chain": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _F, C.POINTER(Rng), _P, _P]),
+    "vaenmf_sample_store": (_I, [_P, _I]),
+    "vaenmf_sample_store_gather": (_I, [_P, _P, _P]),
+    "vaenmf_m_step_stored": (_I, [_P, _P, _P, _P, _P, _P, _P]),
+    "vaenmf_wiener_stored": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vaenmf_rng_fill": (_I, [_P, C.c_uint32, _I, _P, _P, _P]),
     "vaenmf_decode": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "vaenmf_m_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),

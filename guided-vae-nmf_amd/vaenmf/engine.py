@@ -184,6 +184,16 @@ class BatchEngine:
                                     C.byref(rng), _ptr(acc), _stream()))
         return acc
 
+    def sample_store(self, on=True):
+        """Keep the decoded variances of the chain's samples in HBM (see include/vaenmf.h)."""
+        check(lib().vaenmf_sample_store(self._plan, 1 if on else 0))
+
+    def stored_variances(self, R):
+        """Vs of the last chain's samples from the store: device float32 [NT,R,Fs]."""
+        out = torch.empty(self.NT, R, self.Fs, device=self.device, dtype=torch.float32)
+        check(lib().vaenmf_sample_store_gather(self._plan, _ptr(out), _stream()))
+        return out
+
     def rng_fill(self, call, S):
         eps = torch.empty(S, self.NT, LAT, device=self.device, dtype=torch.float32)
         u = torch.empty(S, self.NT, device=self.device, dtype=torch.float32)
@@ -200,6 +210,21 @@ class BatchEngine:
                                   self.Rcap, int(R), _ptr(self.B1), _ptr(self.cost_frames), _stream()))
         return self.cost_frames
 
+    def m_step_stored(self):
+        """M-step over the sample store of the last chain (see include/vaenmf.h)."""
+        check(lib().vaenmf_m_step_stored(self._plan, _ptr(self.X2), _ptr(self.W), _ptr(self.Ht), _ptr(self.g),
+                                         _ptr(self.cost_frames), _stream()))
+        return self.cost_frames
+
+    def wiener_stored(self, want_masks=False):
+        S = torch.empty_like(self.X)
+        N = torch.empty_like(self.X)
+        WFs = torch.empty(self.NT, self.Fs, device=self.device, dtype=torch.float32) if want_masks else None
+        WFn = torch.empty(self.NT, self.Fs, device=self.device, dtype=torch.float32) if want_masks else None
+        check(lib().vaenmf_wiener_stored(self._plan, _ptr(self.W), _ptr(self.Ht), _ptr(self.g), _ptr(self.X), _ptr(S), _ptr(N),
+                                         _ptr(WFs), _ptr(WFn), _stream()))
+        return S, N, WFs, WFn
+
     def wiener(self, R, want_masks=False):
         S = torch.empty_like(self.X)
         N = torch.empty_like(self.X)
@@ -209,14 +234,19 @@ class BatchEngine:
                                   self.Rcap, int(R), _ptr(self.B1), _ptr(self.X), _ptr(S), _ptr(N), _ptr(WFs), _ptr(WFn), _stream()))
         return S, N, WFs, WFn
 
-    def run(self, niter, nsE, biE, nsWF, biWF, var_rw):
-        """Fused EM.run for the whole batch (device RNG).  Returns (cost [U,niter] float64, S_hat, N_hat)."""
+    def run(self, niter, nsE, biE, nsWF, biWF, var_rw, store=None):
+        """Fused EM.run for the whole batch (device RNG).  Returns (cost [U,niter] float64, S_hat, N_hat).
+        store: use the sample-variance store (include/vaenmf.h); default: on in bf16 mode, off in bf16x3 mode."""
         cost = torch.zeros(self.U, niter, device=self.device, dtype=torch.float64)
         S = torch.empty_like(self.X)
         N = torch.empty_like(self.X)
+        if store is None:       # bf16 mode: the chain keeps the samples' variances in HBM, M-step and Wiener filter stream them
+            store = self.precision == _lib.PREC_BF16 and self.F <= 769
+        self.sample_store(store)
         check(lib().vaenmf_em_run(self._plan, _ptr(self.X2), _ptr(self.W), _ptr(self.Ht), _ptr(self.g), _ptr(self.Z),
                                   _ptr(self.B1), _ptr(self.Zs), self.Rcap, int(niter), int(nsE), int(biE), int(nsWF),
                                   int(biWF), float(var_rw), _ptr(self.X), _ptr(S), _ptr(N), _ptr(cost), _stream()))
+        self.sample_store(False)
         return cost, S, N
 
     # ------------------------------------------------------------------ host views (reference shapes)

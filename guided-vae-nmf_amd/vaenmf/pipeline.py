@@ -22,7 +22,8 @@ class Reconstructor:
     def __init__(self, state_dict, x_dim, nmf_rank, niter=100, nsamples_E_step=10, burnin_E_step=30,
                  nsamples_WF=25, burnin_WF=75, var_RW=0.01, model="M1", reference_compat=True,
                  fs=16000, wlen_sec=64e-3, hop_percent=0.25, eps=1e-8, precision="bf16x3", device="cuda:0",
-                 max_frames=1 << 16, max_utts=128):
+                 max_frames=1 << 16, max_utts=128, store=None):
+        self.store = store          # sample-variance store in the fused run: None = the engine's default (on in bf16 mode)
         sd = {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)) for k, v in state_dict.items()}
         self.enc = _encoder_params(sd)
         self.F, self.K, self.niter, self.var_RW, self.eps = int(x_dim), int(nmf_rank), int(niter), var_RW, eps
@@ -57,7 +58,7 @@ class Reconstructor:
         if y is not None:
             eng.set_labels(y)
         eng.encode(self.enc, y)
-        cost, S, N = eng.run(self.niter, self.nsE, self.biE, self.nsW, self.biW, self.var_RW)
+        cost, S, N = eng.run(self.niter, self.nsE, self.biE, self.nsW, self.biW, self.var_RW, store=self.store)
         nfft, hop = vstft.frame_geometry(sample_counts[0], self.fs, self.wlen_sec, self.hop_percent)[:2]
         s_hat = vstft.istft_batch(S, fc, sample_counts, nfft, hop, device=self.device)
         n_hat = vstft.istft_batch(N, fc, sample_counts, nfft, hop, device=self.device)

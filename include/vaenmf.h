@@ -159,6 +159,28 @@ int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* Ht, float* g
 int vaenmf_dense(const float* X, int32_t M, int32_t in, int32_t ldx, const float* Wt, const float* b,
                  int32_t out, int32_t act, float* Y, int32_t ldy, void* stream);
 
+/* Sample-variance store.  With the store enabled, vaenmf_mh_chain also writes the decoded
+ * variances Vs = exp(decoder(Z')) of every post-burn-in proposal (they are in registers
+ * anyway) to a plan-owned buffer VsS DEV [NT][Rs][Fs], Rs = nsamples + 1 -- float rows in
+ * bf16x3 mode, bf16 rows in bf16 mode (half the traffic; rounding of the size the bf16
+ * decoder products carry anyway) -- and a map
+ * src DEV int32 [NT][Rs]: the variances of sample r of frame n (the state after post-burn-in
+ * step r, mcem.py:429-437) are the row VsS[n][src[n][r]].  The M-step and the Wiener
+ * filter can then stream the samples' variances from HBM instead of decoding Zs again
+ * (vaenmf_m_step_stored, vaenmf_wiener_stored; vaenmf_em_run does so by itself).  The store
+ * describes the most recent vaenmf_mh_chain call only.  vaenmf_sample_store_gather copies
+ * the samples' rows out densely, Vs_out DEV float [NT][nsamples][Fs] (what vaenmf_decode
+ * computes from Zs; bins >= F unspecified). */
+int vaenmf_sample_store(vaenmf_plan* plan, int32_t enable);
+int vaenmf_sample_store_gather(vaenmf_plan* plan, float* Vs_out, void* stream);
+/* vaenmf_m_step / vaenmf_wiener over the store of the most recent chain (same updates, same
+ * outputs; the samples are the store's, so no Zs / B1 arguments). */
+int vaenmf_m_step_stored(vaenmf_plan* plan, const float* X2, float* W, float* Ht, float* g,
+                         double* cost_frames, void* stream);
+int vaenmf_wiener_stored(vaenmf_plan* plan, const float* W, const float* Ht, const float* g,
+                         const float* X, float* S_hat, float* N_hat, float* WFs, float* WFn,
+                         void* stream);
+
 /* |X|^2 (mcem.py:47): X DEV complex64 [n], X2 DEV float [n]. */
 int vaenmf_power_spec(const float* X, float* X2, int64_t n, void* stream);
 

@@ -579,3 +579,111 @@ def test_spp_estimator_against_reference():
     assert np.max(np.abs(s[:n0].T - z["mask0"])) < 2e-6 and np.max(np.abs(s[n0:].T - z["mask1"])) < 2e-6
     ref_psd = orc.spp_recursion(z["P1"].T)[0]
     assert np.max(np.abs(psd[n0:] - ref_psd) / (np.abs(ref_psd) + 1e-12)) < 1e-6
+
+
+def test_sample_store_holds_the_samples_variances():
+    """Sample-variance store: after a chain, row src[n][r] of the store is the decoded variance of sample r --
+    the same numbers vaenmf_decode computes from Zs (both modes; ragged batch; burn-in shorter and longer than
+    the sample count) -- and the chain itself is unchanged by storing."""
+    need_gpu()
+    z, params, draws, meta = load_case("m1_f257")
+    F, K = meta["F"], meta["K"]
+    counts, seeds = [37, 64, 70], [5, 6, 7]
+    g = np.random.default_rng(8)
+    Xs = [((g.standard_normal((n, F)) + 1j * g.standard_normal((n, F))) * (1 + 3 * np.exp(-np.arange(F) / 40.0))).astype(np.complex64) for n in counts]
+    W0 = [np.maximum(g.random((F, K)), 1e-8).astype(np.float32) for _ in counts]
+    H0 = [np.maximum(g.random((K, n)), 1e-8).astype(np.float32) for n in counts]
+    for prec in ("bf16x3", "bf16"):
+        for (ns, bi) in ((6, 9), (10, 3), (5, 0)):
+            eng = make_engine(params, F, K, counts, Rcap=12, seeds=seeds, precision=prec)
+            eng.set_spectrogram(Xs)
+            eng.init_nmf(W0, H0)
+            Z0 = eng.Z.clone()
+            eng.mh_chain(ns, bi, 0.01, call=2)
+            Zs_plain, Z_plain = eng.Zs.clone(), eng.Z.clone()
+            eng.Z.copy_(Z0)
+            eng.sample_store(True)
+            eng.mh_chain(ns, bi, 0.01, call=2)
+            assert torch.equal(eng.Zs, Zs_plain) and torch.equal(eng.Z, Z_plain)
+            got = eng.stored_variances(ns)[:, :, :F].cpu().numpy()
+            ref = eng.decode(ns)[:, :, :F].cpu().numpy()
+            assert np.all(np.isfinite(got))
+            # same MFMA products, accumulated with the operands in swapped roles: equal to rounding; bf16 mode
+            # stores bf16 rows (8 significant bits: relative rounding up to 2^-8)
+            assert np.max(np.abs(got - ref) / ref) < (2e-5 if prec == "bf16x3" else 4e-3), (prec, ns, bi)
+            eng.sample_store(False)
+
+
+@pytest.mark.parametrize("F,K,prec", [(257, 8, "bf16x3"), (257, 8, "bf16"), (513, 10, "bf16x3"), (65, 4, "bf16x3"), (257, 32, "bf16")])
+def test_stored_m_step_and_wiener_match_the_decoding_ones(F, K, prec):
+    """vaenmf_m_step_stored / vaenmf_wiener_stored (streaming the chain's stored variances) against
+    vaenmf_m_step / vaenmf_wiener (decoding Zs again) from the same state and the same chain: the same W, H, g,
+    cost and Wiener outputs up to summation order (bf16x3 mode, float rows: 2e-5 relative on the updates, 1e-6 on
+    the cost; bf16 mode, bf16 rows with up to 2^-8 relative rounding per stored variance: 3e-3 / 1e-4)."""
+    need_gpu()
+    tu, tc, tw = (2e-5, 1e-6, 2e-5) if prec == "bf16x3" else (3e-3, 1e-4, 3e-3)
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=3, bias_std=0.1)
+    counts, seeds = [37, 64, 70], [5, 6, 7]
+    g = np.random.default_rng(8)
+    Xs = [((g.standard_normal((n, F)) + 1j * g.standard_normal((n, F))) * (1 + 3 * np.exp(-np.arange(F) / 40.0))).astype(np.complex64) for n in counts]
+    W0 = [np.maximum(g.random((F, K)), 1e-8).astype(np.float32) for _ in counts]
+    H0 = [np.maximum(g.random((K, n)), 1e-8).astype(np.float32) for n in counts]
+
+    def prep():
+        eng = make_engine(params, F, K, counts, Rcap=27, seeds=seeds, precision=prec)
+        eng.set_spectrogram(Xs)
+        eng.init_nmf(W0, H0)
+        eng.sample_store(True)
+        return eng
+
+    for (ns, bi) in ((10, 6), (7, 0), (27, 3)):
+        ea, eb = prep(), prep()
+        for it in range(2):
+            for e in (ea, eb):
+                e.mh_chain(ns, bi, 0.01, call=it)
+            assert torch.equal(ea.Zs, eb.Zs)
+            ca = ea.m_step(ns).clone()
+            cb = eb.m_step_stored().clone()
+            for name in ("W", "Ht", "g"):
+                x, y = getattr(ea, name).cpu().numpy(), getattr(eb, name).cpu().numpy()
+                assert np.max(np.abs(x - y) / (np.abs(x) + 1e-20)) < tu, (name, ns, bi, it)
+            assert np.max(np.abs(ca.cpu().numpy() - cb.cpu().numpy()) / np.abs(ca.cpu().numpy())) < tc
+            # keep the two engines on the same trajectory
+            for name in ("W", "Ht", "g"):
+                getattr(eb, name).copy_(getattr(ea, name))
+        for e in (ea, eb):
+            e.mh_chain(ns, bi, 0.01, call=9, update_Z=False)
+        Sa, Na, WFsa, WFna = ea.wiener(ns, want_masks=True)
+        Sb, Nb, WFsb, WFnb = eb.wiener_stored(want_masks=True)
+        assert float((WFsa[:, :F] - WFsb[:, :F]).abs().max()) < tw and float((WFna[:, :F] - WFnb[:, :F]).abs().max()) < tw
+        assert nrm_err(Sb.cpu().numpy(), Sa.cpu().numpy()) < tw and nrm_err(Nb.cpu().numpy(), Na.cpu().numpy()) < tw
+        assert float(Sb[:, F:].abs().max()) == 0.0 and float(WFsb[:, F:].abs().max()) == 0.0
+
+
+def test_fused_run_with_the_sample_store():
+    """vaenmf_em_run with the store on (chain stores, streaming M-step and Wiener filter) against the run that
+    decodes the samples again: same device RNG streams; the trajectories agree to rounding for the first
+    iterations (they are chaotic beyond: a flipped accept decision changes a frame's chain)."""
+    need_gpu()
+    z, params, draws, meta = load_case("m1_f257")
+    F, K = meta["F"], meta["K"]
+    counts, seeds = [37, 64, 50], [5, 6, 7]
+    g = np.random.default_rng(8)
+    Xs = [((g.standard_normal((n, F)) + 1j * g.standard_normal((n, F))) * (1 + 3 * np.exp(-np.arange(F) / 40.0))).astype(np.complex64) for n in counts]
+    W0 = [np.maximum(g.random((F, K)), 1e-8).astype(np.float32) for _ in counts]
+    H0 = [np.maximum(g.random((K, n)), 1e-8).astype(np.float32) for n in counts]
+
+    def run(store, niter):
+        eng = make_engine(params, F, K, counts, Rcap=12, seeds=seeds)
+        eng.set_spectrogram(Xs)
+        eng.init_nmf(W0, H0)
+        return eng.run(niter, 6, 5, 12, 7, 0.01, store=store)
+
+    ca, Sa, Na = run(False, 1)
+    cb, Sb, Nb = run(True, 1)
+    assert np.max(np.abs(ca.cpu().numpy() - cb.cpu().numpy()) / np.abs(ca.cpu().numpy())) < 1e-6
+    assert nrm_err(Sb.cpu().numpy(), Sa.cpu().numpy()) < 1e-3
+    ca, Sa, Na = run(False, 4)
+    cb, Sb, Nb = run(True, 4)
+    assert np.max(np.abs(ca.cpu().numpy() - cb.cpu().numpy()) / np.abs(ca.cpu().numpy())) < 5e-3
+    assert np.all(np.isfinite(Sb.cpu().numpy())) and np.all(np.isfinite(cb.cpu().numpy()))

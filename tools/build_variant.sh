@@ -4,6 +4,6 @@
 set -e
 tag=$1; shift
 cd "$(dirname "$0")/../guided-vae-nmf_amd/csrc"
-for s in engine aux plan labels; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 "$@" -c $s.hip -o /tmp/${s}_$tag.o & done
+for s in engine aux plan labels stream; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 "$@" -c $s.hip -o /tmp/${s}_$tag.o & done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../vaenmf/libvaenmf_$tag.so /tmp/engine_$tag.o /tmp/aux_$tag.o /tmp/plan_$tag.o /tmp/labels_$tag.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../vaenmf/libvaenmf_$tag.so /tmp/engine_$tag.o /tmp/aux_$tag.o /tmp/plan_$tag.o /tmp/labels_$tag.o /tmp/stream_$tag.o
