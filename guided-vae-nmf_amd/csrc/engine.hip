@@ -342,7 +342,7 @@ struct ChainArgs {
   const float* Vb;           // external noise variance [NT][Fs] (the *_noNMF variants, mcem.py:493-760) or null: Vb = W H
   float *Z, *Zs, *acc_out;
   void* VsS;                 // sample-variance store [NT][Rs][Fs] (float in bf16x3 mode, bf16 in bf16 mode) or null
-  int32_t* src;              // [NT][Rs]: slot of VsS that holds the variances of sample r
+  int32_t* src;              // [Rs][NT] (sample-major): slot of VsS that holds the variances of sample r of frame n
   int Rs;                    // slots per frame: nsamples + 1
   const int32_t *tile_utt, *tile_n0, *tile_cnt, *frame_off;
   const uint64_t* utt_seed;
@@ -456,16 +456,21 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
   // ---- sample-variance store (STORE): the decoded variances Vs = exp(decoder(Z')) of every post-burn-in
   // proposal go to HBM (slot r of the frame for step burnin + r) so that the M-step streams them instead of
   // decoding the samples again; slot R holds the state the chain is in when the burn-in ends (one extra
-  // evaluation pass; the initial state itself when there is no burn-in).  src[frame][r] names the slot of the
+  // evaluation pass; the initial state itself when there is no burn-in).  src[r][frame] names the slot of the
   // state the chain is in after post-burn-in step r (mcem.py:429-437).
   // The rows are float in bf16x3 mode and bf16 in bf16 mode (half the HBM traffic; the decoder's own bf16 products
   // already carry errors of that size, and each stored value enters the M-step inside a sum over the samples).
   using store_t = typename std::conditional<SPLIT, float, __bf16>::type;
-  store_t* vsrow[2] = {nullptr, nullptr};
+  // (addresses: uniform base + 32-bit element offset of this lane's first bin in slot 0 of its frame -- the host
+  // keeps the store below 4 GB -- so the store costs two VGPRs of state, not eight)
+  // Lanes without a frame write to a spare frame block behind the last one: the tile stores then need no
+  // per-lane predicate (an exec-masked store after every bin tile splits the epilogue into small basic blocks
+  // and costs the MFMA / VALU interleave).
+  uint32_t voff[2] = {0u, 0u};
   int cur_src[2] = {a.nsamples, a.nsamples};
   if (STORE) {
 #pragma unroll
-    for (int fg = 0; fg < 2; ++fg) vsrow[fg] = fvalid[fg] ? reinterpret_cast<store_t*>(a.VsS) + (size_t)nrow[fg] * a.Rs * a.Fs : nullptr;
+    for (int fg = 0; fg < 2; ++fg) voff[fg] = (uint32_t)(fvalid[fg] ? nrow[fg] : a.NT) * (uint32_t)(a.Rs * a.Fs) + 4u * q;
   }
   // ---- noise streams: thread of the team <-> (frame of the team, latent quad); 256 streams
   const int sid = threadIdx.x - d.team * NW * 64, sfr = sid >> 3, squad = sid & 7;
@@ -501,13 +506,11 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
   // E(z) = sum_f [log Vx + X2/Vx] per frame (fp64 accumulation: the reference sums the
   // per-bin DIFFERENCES of two states, mcem.py:415-416; summing each state separately
   // needs the extra bits to keep the same absolute accuracy).
-  // next_step: the MH step whose noise is drawn during this evaluation (>= S: none); slot: store slot or -1
-  auto energy = [&](const float (&zz)[2][8], double (&E)[2], int next_step, int slot) {
-    store_t* vdst[2] = {nullptr, nullptr};
-    if (STORE) {
-#pragma unroll
-      for (int fg = 0; fg < 2; ++fg) vdst[fg] = (slot >= 0 && vsrow[fg]) ? vsrow[fg] + (size_t)slot * a.Fs : nullptr;
-    }
+  // next_step: the MH step whose noise is drawn during this evaluation (>= S: none); slot: store slot (DOST)
+  auto energy = [&](const float (&zz)[2][8], double (&E)[2], int next_step, int slot, auto dost) {
+    constexpr bool DOST = STORE && decltype(dost)::value;
+    store_t* const vbase = reinterpret_cast<store_t*>(a.VsS);
+    const uint32_t soff = DOST ? (uint32_t)(slot * a.Fs) : 0u;
     bf16x8 zhi[2], zlo[2];
     split8<SPLIT>(zz[0], zhi[0], zlo[0]);
     split8<SPLIT>(zz[1], zhi[1], zlo[1]);
@@ -534,9 +537,10 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
               pl += fast_log2(pp);
               px += (x2[i][fg][t] * v1 + x2[i][fg][t + 1] * v0) * fast_rcp(pp);
             }
-            if (STORE && vdst[fg]) {
-              if (SPLIT) *reinterpret_cast<f32x4*>(vdst[fg] + 16 * (w + NW * i) + 4 * q) = ev;
-              else *reinterpret_cast<bf16x4*>(vdst[fg] + 16 * (w + NW * i) + 4 * q) = bf16x4{(__bf16)ev[0], (__bf16)ev[1], (__bf16)ev[2], (__bf16)ev[3]};
+            if (DOST) {
+              store_t* dst = vbase + (voff[fg] + (soff + 16u * (uint32_t)(w + NW * i)));
+              if (SPLIT) *reinterpret_cast<f32x4*>(dst) = ev;
+              else *reinterpret_cast<bf16x4*>(dst) = bf16x4{(__bf16)ev[0], (__bf16)ev[1], (__bf16)ev[2], (__bf16)ev[3]};
             }
             e[fg] += (double)(pl * LN2_F + px);
           }
@@ -549,7 +553,24 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
         const float vx = gn[fg] * vs + vbn[fg];
         const float term = fast_log(vx) + x2n[fg] * fast_rcp(vx);
         e[fg] += (w == 0 && q == 0) ? (double)term : 0.0;        // counted once per frame
-        if (STORE && vdst[fg] && w == 0 && q == 0) vdst[fg][dw.F - 1] = (store_t)vs;
+        if (DOST && w == 2 && q == 0) {      // (the per-step bookkeeping stores are spread over the waves of the team)
+          // the whole 16-bin tail of the row (the bin and its zero padding) in full 32-byte sectors: a lone 2- or
+          // 4-byte store per frame and step is a read-modify-write in the memory system (measured: 5 % of the launch)
+          store_t* dst = vbase + (voff[fg] + (soff + (uint32_t)dw.Fm));
+          if (SPLIT) {
+            *reinterpret_cast<f32x4*>(dst) = f32x4{vs, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 1; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + 4 * j) = f32x4{0.f, 0.f, 0.f, 0.f};
+          } else {
+            bf16x8 t8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t8[j] = (__bf16)0.f;
+            bf16x8 h8 = t8;
+            h8[0] = (__bf16)vs;
+            *reinterpret_cast<bf16x8*>(dst) = h8;
+            *reinterpret_cast<bf16x8*>(dst + 8) = t8;
+          }
+        }
       }
     }
     const int par = ecount & 1;
@@ -602,7 +623,9 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
     const float uu0 = (m >= 0 && !re) ? L.u[c] : 1.f, uu1 = (m >= 0 && !re) ? L.u[16 + c] : 1.f;
     double Ep[2];
     const int slot = !STORE ? -1 : (re ? a.nsamples : (m >= a.burnin ? m - a.burnin : ((m < 0 && a.burnin == 0) ? a.nsamples : -1)));
-    energy(zp, Ep, re ? S : m + 1, slot);             // mcem.py:410-412 (draws the next step's noise inside)
+    // mcem.py:410-412 (draws the next step's noise inside); two copies of the evaluation, with and without stores
+    if (STORE && slot >= 0) energy(zp, Ep, re ? S : m + 1, slot, std::true_type{});
+    else energy(zp, Ep, re ? S : m + 1, slot, std::false_type{});
     if (re) continue;                                 // (the state, its energy and the pending noise are untouched)
 #pragma unroll
     for (int fg = 0; fg < 2; ++fg) {
@@ -616,14 +639,14 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
       const float accp = (float)(Ecur[fg] - Ep[fg]) + 0.5f * pr;
       const float uu = fg == 0 ? uu0 : uu1;
       const bool ok = m < 0 || fast_log(uu) < accp;   // mcem.py:420
-      if (a.acc_out && m >= 0 && w == 0 && q == 0 && fvalid[fg]) a.acc_out[(size_t)m * a.NT + nrow[fg]] = accp;
+      if (a.acc_out && m >= 0 && w == 3 && q == 0 && fvalid[fg]) a.acc_out[(size_t)m * a.NT + nrow[fg]] = accp;
       if (ok) {                                       // mcem.py:429-433
 #pragma unroll
         for (int j = 0; j < 8; ++j) z[fg][j] = z[fg][j] + sd * e8[fg][j];
         Ecur[fg] = Ep[fg];
         if (STORE && m >= a.burnin) cur_src[fg] = m - a.burnin;
       }
-      if (STORE && m >= a.burnin && w == 0 && q == 0 && fvalid[fg]) a.src[(size_t)nrow[fg] * a.Rs + (m - a.burnin)] = cur_src[fg];
+      if (STORE && m >= a.burnin && w == 1 && q == 0 && fvalid[fg]) a.src[(size_t)(m - a.burnin) * a.NT + nrow[fg]] = cur_src[fg];   // [r][n]: the 16 frames of a column group fill one line
       if (m >= a.burnin && w == 0 && fvalid[fg]) {    // mcem.py:435-437
         float* dst = a.Zs + ((size_t)nrow[fg] * a.Rcap + (m - a.burnin)) * LAT;
         *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{z[fg][0], z[fg][1], z[fg][2], z[fg][3]};
@@ -1377,7 +1400,9 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
   if (p->store_on) {                                    // sample-variance store: grown on demand, reused across calls
     const int Rs = nsamples + 1;
     const size_t esz = split ? sizeof(float) : sizeof(__bf16);
-    const size_t need_v = (size_t)p->NT * Rs * p->Fs * esz, need_s = (size_t)p->NT * Rs;
+    const size_t need_v = (size_t)(p->NT + 1) * Rs * p->Fs * esz, need_s = (size_t)p->NT * Rs;   // + a spare block (idle lanes)
+    VN_REQUIRE((size_t)(p->NT + 1) * Rs * p->Fs < (1ull << 32), "sample store: %d frames x %d slots x %d bins exceeds the 32-bit "
+               "element offsets of the chain kernel; bind a smaller batch or switch the store off", p->NT, Rs, p->Fs);
     if (need_v > p->VsS_cap) {
       if (p->VsS) VN_CHECK_HIP(hipFree(p->VsS));
       p->VsS = nullptr; p->VsS_cap = 0;
@@ -1416,7 +1441,7 @@ template <typename ST>
 __global__ void store_gather_kernel(const ST* __restrict__ VsS, const int32_t* __restrict__ src, int NT, int R, int Rs, int Fs,
                                     float* __restrict__ out) {
   const int n = blockIdx.x / R, r = blockIdx.x - n * R;
-  const ST* row = VsS + ((size_t)n * Rs + src[(size_t)n * Rs + r]) * Fs;
+  const ST* row = VsS + ((size_t)n * Rs + src[(size_t)r * NT + n]) * Fs;
   for (int f = threadIdx.x; f < Fs; f += blockDim.x) out[((size_t)n * R + r) * Fs + f] = (float)row[f];
 }
 }  // namespace

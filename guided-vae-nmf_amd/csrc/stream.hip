@@ -20,7 +20,7 @@ namespace {
 
 struct StreamArgs {
   const void* VsS;             // [NT][Rs][Fs], float or bf16 (template ST)
-  const int32_t* src;          // [NT][Rs]
+  const int32_t* src;          // [Rs][NT] (sample-major)
   const float *X2, *W, *normW, *Vb, *X;
   float *Ht, *g, *A1, *P, *S_hat, *N_hat, *WFs, *WFn;
   double* cost_frames;
@@ -140,11 +140,12 @@ struct RowBatch {
   raw_t raw[RB][NCH];
   float xr;                    // lane j: extra bin (F-1) of row j of the batch
   int nr;
-  // rows r0 .. r0+nr-1 of the frame whose store block starts at `base`; slot map row `srow`
+  // rows r0 .. r0+nr-1 of the frame whose store block starts at `base`; scol = the frame's column of the
+  // sample-major slot map (stride NT)
   template <typename FC>
-  __device__ __forceinline__ void load(const FC& fc, const ST* base, const int32_t* srow, int r0, int R) {
+  __device__ __forceinline__ void load(const FC& fc, const ST* base, const int32_t* scol, int r0, int R) {
     nr = R - r0 < RB ? R - r0 : RB;
-    const int sl = fc.lane < nr ? srow[r0 + fc.lane] : srow[r0];
+    const int sl = scol[(size_t)(r0 + (fc.lane < nr ? fc.lane : 0)) * fc.a.NT];
     xr = fc.has_x ? (float)base[(size_t)sl * fc.a.Fs + fc.a.F - 1] : 0.f;
 #pragma unroll
     for (int r = 0; r < RB; ++r)
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void wstats_stream_kernel(const StreamArgs a) 
   wave_frames(a.NT, n_beg, n_end);
   for (int n = n_beg; n < n_end; ++n) {
     const ST* base = reinterpret_cast<const ST*>(a.VsS) + (size_t)n * a.Rs * a.Fs;
-    const int32_t* srow = a.src + (size_t)n * a.Rs;
+    const int32_t* srow = a.src + n;
     RBt rb;
     rb.load(fc, base, srow, 0, a.R);                 // (issued first: the longest latency of the frame)
     const int utt = a.frame_utt[n];
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void hg_stream_kernel(const StreamArgs a) {
   const bool one = a.R <= RBt::RB;                    // the frame fits one batch: its rows are read once
   for (int n = n_beg; n < n_end; ++n) {
     const ST* base = reinterpret_cast<const ST*>(a.VsS) + (size_t)n * a.Rs * a.Fs;
-    const int32_t* srow = a.src + (size_t)n * a.Rs;
+    const int32_t* srow = a.src + n;
     RBt rb;
     rb.load(fc, base, srow, 0, a.R);
     const int utt = a.frame_utt[n];
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256) void wf_stream_kernel(const StreamArgs a) {
   const float invR = 1.0f / (float)a.R;
   for (int n = n_beg; n < n_end; ++n) {
     const ST* base = reinterpret_cast<const ST*>(a.VsS) + (size_t)n * a.Rs * a.Fs;
-    const int32_t* srow = a.src + (size_t)n * a.Rs;
+    const int32_t* srow = a.src + n;
     RBt rb;
     rb.load(fc, base, srow, 0, a.R);
     const int utt = a.frame_utt[n];

@@ -164,8 +164,8 @@ int vaenmf_dense(const float* X, int32_t M, int32_t in, int32_t ldx, const float
  * anyway) to a plan-owned buffer VsS DEV [NT][Rs][Fs], Rs = nsamples + 1 -- float rows in
  * bf16x3 mode, bf16 rows in bf16 mode (half the traffic; rounding of the size the bf16
  * decoder products carry anyway) -- and a map
- * src DEV int32 [NT][Rs]: the variances of sample r of frame n (the state after post-burn-in
- * step r, mcem.py:429-437) are the row VsS[n][src[n][r]].  The M-step and the Wiener
+ * src DEV int32 [Rs][NT]: the variances of sample r of frame n (the state after post-burn-in
+ * step r, mcem.py:429-437) are the row VsS[n][src[r][n]].  The M-step and the Wiener
  * filter can then stream the samples' variances from HBM instead of decoding Zs again
  * (vaenmf_m_step_stored, vaenmf_wiener_stored; vaenmf_em_run does so by itself).  The store
  * describes the most recent vaenmf_mh_chain call only.  vaenmf_sample_store_gather copies
