@@ -15,6 +15,12 @@
 // Bins of the odd last bin and the padding (f >= Fm: F-1 when F = 16k+1) are handled as one extra
 // element that every lane computes redundantly (same address: a broadcast load).
 #include "common.h"
+#ifndef VN_HG_WAVES
+#define VN_HG_WAVES 4      // minimum waves per SIMD asked of the compiler (register cap 512 / waves)
+#endif
+#ifndef VN_WS_WAVES
+#define VN_WS_WAVES 4
+#endif
 
 namespace {
 
@@ -175,7 +181,7 @@ __device__ __forceinline__ void wave_frames(int NT, int& n_beg, int& n_end) {
 }
 
 template <int NCH, int KP, typename ST>
-__global__ __launch_bounds__(256) void wstats_stream_kernel(const StreamArgs a) {
+__global__ __launch_bounds__(256, VN_WS_WAVES) void wstats_stream_kernel(const StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   FrameCtx<NCH, KP, ST> fc(a, wlds + (size_t)(threadIdx.x >> 6) * a.Fs * KP);
   using RBt = RowBatch<NCH, ST>;
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256) void wstats_stream_kernel(const StreamArgs a) 
 }
 
 template <int NCH, int KP, typename ST>
-__global__ __launch_bounds__(256) void hg_stream_kernel(const StreamArgs a) {
+__global__ __launch_bounds__(256, VN_HG_WAVES) void hg_stream_kernel(const StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   FrameCtx<NCH, KP, ST> fc(a, wlds + (size_t)(threadIdx.x >> 6) * a.Fs * KP);
   using RBt = RowBatch<NCH, ST>;
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(256) void hg_stream_kernel(const StreamArgs a) {
 }
 
 template <int NCH, int KP, typename ST>
-__global__ __launch_bounds__(256) void wf_stream_kernel(const StreamArgs a) {
+__global__ __launch_bounds__(256, VN_WS_WAVES) void wf_stream_kernel(const StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   FrameCtx<NCH, KP, ST> fc(a, wlds + (size_t)(threadIdx.x >> 6) * a.Fs * KP);
   using RBt = RowBatch<NCH, ST>;
