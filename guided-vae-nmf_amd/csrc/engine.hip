@@ -1520,15 +1520,16 @@ extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* H
   vaenmf_rng rng = {VAENMF_RNG_DEVICE, 0, nullptr, nullptr};
   // with the sample store on (vaenmf_sample_store), the chain leaves the samples' variances in HBM and the
   // M-step / Wiener filter stream them; otherwise they decode Zs again
-  const bool stored = p->store_on;
+  // (a batch too large for the store's 32-bit element offsets, or for the streaming kernels' bin range, decodes)
+  auto fits = [&](int ns) { return (size_t)(p->NT + 1) * (ns + 1) * p->Fs < (1ull << 32) && p->Fm <= 768; };
+  const bool want = p->store_on, stored = want && fits(nsE) && fits(nsWF);
+  p->store_on = stored;
+  struct Restore { vaenmf_plan* p; bool v; ~Restore() { p->store_on = v; } } restore{p, want};
   for (int it = 0; it < niter; ++it) {                  // EM.run, mcem.py:159-165
     rng.call = (uint32_t)it;
-    p->store_on = stored;
-    if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, 1, B1, Zs, Rcap, nsE, biE, var_rw, &rng, nullptr, stream)) { p->store_on = stored; return e; }
-    int e = p->store_on ? vaenmf_m_step_stored(p, X2, W, Ht, g, p->cost_frames, stream)
-                        : vaenmf_m_step(p, X2, W, Ht, g, Zs, Rcap, nsE, B1, p->cost_frames, stream);
-    p->store_on = stored;
-    if (e) return e;
+    if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, 1, B1, Zs, Rcap, nsE, biE, var_rw, &rng, nullptr, stream)) return e;
+    if (int e = stored ? vaenmf_m_step_stored(p, X2, W, Ht, g, p->cost_frames, stream)
+                       : vaenmf_m_step(p, X2, W, Ht, g, Zs, Rcap, nsE, B1, p->cost_frames, stream)) return e;
     if (cost) if (int e2 = vn_launch_cost_reduce(p, p->cost_frames, nsE, cost, niter, it, st)) return e2;
   }
   rng.call = (uint32_t)niter;                           // compute_WF(sample=True), mcem.py:173

@@ -3,7 +3,11 @@ import csv, glob, collections, sys, os, json
 tag = sys.argv[1]; src = sys.argv[2]; out = sys.argv[3]
 lines = []
 P = lambda *a: lines.append(" ".join(str(x) for x in a))
-short = lambda k: k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]
+def short(k):
+    k = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    m = __import__("re").match(r"_ZN12_GLOBAL__N_1\d+(\w+?_kernel)I(.*?)EEv", k)      # names rocprofv3 left mangled
+    if m: k = m.group(1) + "<" + m.group(2).replace("Li", "").replace("E", ",").replace("DF16b", "bf16").replace("f", "float").strip(",") + ">"
+    return k[:90]
 st = glob.glob(os.path.join(src, "trace/*/*_kernel_stats.csv"))[0]
 P("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --precision", tag)
 P("# (per kernel: calls, total ms, average us, % of GPU kernel time)")
@@ -12,7 +16,7 @@ for r in csv.DictReader(open(st)):
                                                                   float(r["AverageNs"]) / 1e3, r["Percentage"]))
 P("")
 P("# bench line of the traced run:")
-P(open(os.path.join(src, "bench_trace.log")).read().strip().splitlines()[-1])
+P([l for l in open(os.path.join(src, "bench_trace.log")).read().splitlines() if l.startswith("{")][-1])
 def pmc(name):
     f = glob.glob(os.path.join(src, name, "*/*_counter_collection.csv"))[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); nd = collections.defaultdict(set); dur = collections.defaultdict(float)
@@ -26,7 +30,7 @@ P("# HBM traffic (separate --pmc passes, niter=10): FETCH_SIZE and WRITE_SIZE ar
 P("# MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads on gfx950 -> doubled below")
 fa, fn, _ = pmc("pmc_fetch"); wa, wn, _ = pmc("pmc_write")
 for k in fa:
-    if not any(s in k for s in ("mh_chain", "decode_kernel", "w_update", "w_partial")): continue
+    if not any(s in k for s in ("mh_chain", "decode_kernel", "stream_kernel", "w_update", "w_partial")): continue
     n = len(fn[k]); f = fa[k]["FETCH_SIZE"] / n; w = wa.get(k, {}).get("WRITE_SIZE", 0.0) / max(len(wn.get(k, [1])), 1)
     P("%-92s launches %4d  FETCH_SIZE/launch %10.1f KB (x2 = %8.2f MB)  WRITE_SIZE/launch %10.1f KB  => HBM %8.2f MB/launch"
       % (k, n, f, 2 * f / 1024, w, (2 * f + w) / 1024))
@@ -41,7 +45,7 @@ P("")
 P("# SQ counters (niter=10), summed over launches; *_CYCLES of waves are quad-cycles, VALU_MFMA_BUSY in cycles")
 sa, sn, _ = pmc("pmc_sq")
 for k in sa:
-    if not any(s in k for s in ("mh_chain", "decode_kernel")): continue
+    if not any(s in k for s in ("mh_chain", "decode_kernel", "stream_kernel")): continue
     v = sa[k]; wc = v["SQ_WAVE_CYCLES"]
     P("%-92s launches %d" % (k, len(sn[k])))
     for c in sorted(v): P("    %-28s %16.0f   (%.3f of SQ_WAVE_CYCLES)" % (c, v[c], v[c] / wc))
