@@ -34,6 +34,7 @@ struct StreamArgs {
   int NT, R, Rs, F, Fm, Fs, K;
   int gains_only;              // the *_noNMF M-step (mcem.py:543-578): Vb given, only g moves
   int store_f32;               // rows are float (bf16x3 mode) rather than bf16
+  int w_blk_lds;               // rank > 8: W of the workgroup's first utterance is staged in LDS
 };
 
 __device__ __forceinline__ float wave_sum(float v) { return sum_rows4(sum_row16(v)); }
@@ -45,22 +46,41 @@ struct FrameCtx {
   bool cv[NCH];                // chunk c holds real bins for this lane
   int f0[NCH];
   bool has_x;                  // an extra bin F-1 beside the 4-bin chunks
-  // W of the utterance the wavefront is in, in a wave-private piece of LDS (rank <= 8; no barrier: only this
-  // wavefront touches it).  Read from global memory per frame the rows dominate the L1 traffic: a lane's 4 rows
-  // are 128 B from the next lane's, so every load instruction touches 64 cache lines -- ~3500 line accesses per
-  // frame against ~120 for the variances.
-  static constexpr bool WLDS = KP <= 8;
+  // W of the utterance in LDS.  Read from global memory per frame the rows dominate the L1 traffic: a lane's 4
+  // rows are 128 B (rank 8) from the next lane's, so every load instruction touches 64 cache lines -- ~3500 line
+  // accesses per frame against ~120 for the variances.
+  //   rank <= 8: a wave-private piece, refilled by the wavefront when it enters another utterance (no barrier);
+  //   rank > 8 : one copy per workgroup, of the utterance of the workgroup's first frame (staged by the kernel
+  //              prologue when it fits); a wavefront in another utterance reads global memory.
+  static constexpr bool WPRIV = KP <= 8;
   float* wl;                   // [Fs][KP]
-  int wutt;
+  int wutt, blk_utt;
+  bool in_lds;                 // wave-uniform: this frame's W rows are the ones in LDS
   __device__ FrameCtx(const StreamArgs& a_, float* wl_) : a(a_), wl(wl_) {
     lane = threadIdx.x & 63;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) { f0[c] = 256 * c + 4 * lane; cv[c] = f0[c] < a.Fm; }
     has_x = a.F != a.Fm;
     wutt = -1;
+    blk_utt = -1;
+    in_lds = false;
+  }
+  // workgroup prologue (rank > 8): stage W of the utterance of the workgroup's first frame
+  __device__ __forceinline__ void stage_block_w() {
+    if (WPRIV || !a.w_blk_lds) return;
+    const int wpb = blockDim.x >> 6, nw = gridDim.x * wpb, per = (a.NT + nw - 1) / nw;
+    const int n_first = blockIdx.x * wpb * per;
+    if (n_first < a.NT) {
+      blk_utt = a.frame_utt[n_first];
+      const f32x4* src = reinterpret_cast<const f32x4*>(a.W + (size_t)blk_utt * a.Fs * KP);
+      for (int e = threadIdx.x; e < a.Fs * KP / 4; e += blockDim.x) reinterpret_cast<f32x4*>(wl)[e] = src[e];
+    }
+    __syncthreads();
   }
   __device__ __forceinline__ void set_utt(int utt) {        // wave-uniform
-    if (!WLDS || utt == wutt) return;
+    if (!WPRIV) { in_lds = utt == blk_utt; return; }
+    in_lds = true;
+    if (utt == wutt) return;
     wutt = utt;
     __builtin_amdgcn_wave_barrier();                        // earlier reads of the previous utterance's rows
     const f32x4* src = reinterpret_cast<const f32x4*>(a.W + (size_t)utt * a.Fs * KP);
@@ -68,14 +88,13 @@ struct FrameCtx {
     __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the rows are in LDS (gfx9 encoding)
     __builtin_amdgcn_wave_barrier();
   }
-  __device__ __forceinline__ float w_at(int utt, int c, int t, int k) const {
-    return WLDS ? wl[(f0[c] + t) * KP + k] : a.W[((size_t)utt * a.Fs + f0[c] + t) * KP + k];
-  }
-  __device__ __forceinline__ float wx_at(int utt, int k) const {
-    return WLDS ? wl[(a.F - 1) * KP + k] : a.W[((size_t)utt * a.Fs + a.F - 1) * KP + k];
+  template <bool L>
+  __device__ __forceinline__ const float* w_row(int utt, int f) const {
+    return L ? wl + f * KP : a.W + ((size_t)utt * a.Fs + f) * KP;
   }
   // Vb = sum_k W[f,k] h[k] for this lane's bins (+ the extra bin); set_utt(utt) first
-  __device__ __forceinline__ void noise_var(int utt, const float (&h)[KP], f32x4 (&vb)[NCH], float& vbx) const {
+  template <bool L>
+  __device__ __forceinline__ void noise_var_(int utt, const float (&h)[KP], f32x4 (&vb)[NCH], float& vbx) const {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       vb[c] = f32x4{1.f, 1.f, 1.f, 1.f};
@@ -83,7 +102,7 @@ struct FrameCtx {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           float v = 0.f;
-          const float* wrow = WLDS ? wl + (f0[c] + t) * KP : a.W + ((size_t)utt * a.Fs + f0[c] + t) * KP;
+          const float* wrow = w_row<L>(utt, f0[c] + t);
 #pragma unroll
           for (int k = 0; k < KP; k += 4) {
             const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow + k);
@@ -95,11 +114,42 @@ struct FrameCtx {
     }
     vbx = 1.f;
     if (has_x) {
+      const float* wrow = w_row<L>(utt, a.F - 1);
       float v = 0.f;
 #pragma unroll
-      for (int k = 0; k < KP; ++k) v += wx_at(utt, k) * h[k];
+      for (int k = 0; k < KP; ++k) v += wrow[k] * h[k];
       vbx = v;
     }
+  }
+  __device__ __forceinline__ void noise_var(int utt, const float (&h)[KP], f32x4 (&vb)[NCH], float& vbx) const {
+    if (WPRIV || in_lds) noise_var_<true>(utt, h, vb, vbx);
+    else noise_var_<false>(utt, h, vb, vbx);
+  }
+  // num_k = sum_f W[f,k] P[f], den_k = sum_f W[f,k] A[f] over this lane's bins (+ the extra bin in lane 0's terms)
+  template <bool L>
+  __device__ __forceinline__ void w_dot_(int utt, int k, const f32x4 (&P)[NCH], const f32x4 (&A)[NCH], float px, float ax,
+                                         float& nu, float& de) const {
+    nu = de = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (cv[c]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float w = w_row<L>(utt, f0[c] + t)[k];
+          nu += w * P[c][t];
+          de += w * A[c][t];
+        }
+      }
+    if (has_x) {
+      const float w = w_row<L>(utt, a.F - 1)[k];
+      nu += w * px;
+      de += w * ax;
+    }
+  }
+  __device__ __forceinline__ void w_dot(int utt, int k, const f32x4 (&P)[NCH], const f32x4 (&A)[NCH], float px, float ax,
+                                        float& nu, float& de) const {
+    if (WPRIV || in_lds) w_dot_<true>(utt, k, P, A, px, ax, nu, de);
+    else w_dot_<false>(utt, k, P, A, px, ax, nu, de);
   }
   __device__ __forceinline__ void ext_var(int n, f32x4 (&vb)[NCH], float& vbx) const {   // caller-given Vb (noNMF)
 #pragma unroll
@@ -181,9 +231,10 @@ __device__ __forceinline__ void wave_frames(int NT, int& n_beg, int& n_end) {
 }
 
 template <int NCH, int KP, typename ST>
-__global__ __launch_bounds__(256, VN_WS_WAVES) void wstats_stream_kernel(const StreamArgs a) {
+__global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void wstats_stream_kernel(const StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
-  FrameCtx<NCH, KP, ST> fc(a, wlds + (size_t)(threadIdx.x >> 6) * a.Fs * KP);
+  FrameCtx<NCH, KP, ST> fc(a, wlds + (KP <= 8 ? (size_t)(threadIdx.x >> 6) * a.Fs * KP : 0));
+  fc.stage_block_w();
   using RBt = RowBatch<NCH, ST>;
   int n_beg, n_end;
   wave_frames(a.NT, n_beg, n_end);
@@ -238,9 +289,10 @@ __global__ __launch_bounds__(256, VN_WS_WAVES) void wstats_stream_kernel(const S
 }
 
 template <int NCH, int KP, typename ST>
-__global__ __launch_bounds__(256, VN_HG_WAVES) void hg_stream_kernel(const StreamArgs a) {
+__global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void hg_stream_kernel(const StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
-  FrameCtx<NCH, KP, ST> fc(a, wlds + (size_t)(threadIdx.x >> 6) * a.Fs * KP);
+  FrameCtx<NCH, KP, ST> fc(a, wlds + (KP <= 8 ? (size_t)(threadIdx.x >> 6) * a.Fs * KP : 0));
+  fc.stage_block_w();
   using RBt = RowBatch<NCH, ST>;
   int n_beg, n_end;
   wave_frames(a.NT, n_beg, n_end);
@@ -306,22 +358,8 @@ __global__ __launch_bounds__(256, VN_HG_WAVES) void hg_stream_kernel(const Strea
       float hn[KP];
 #pragma unroll
       for (int k = 0; k < KP; ++k) {
-        float nu = 0.f, de = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-          if (fc.cv[c]) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float w = fc.w_at(utt, c, t, k);
-              nu += w * a2[c][t];
-              de += w * a1[c][t];
-            }
-          }
-        if (fc.has_x) {
-          const float w = fc.wx_at(utt, k);
-          nu += w * a2x;
-          de += w * a1x;
-        }
+        float nu, de;
+        fc.w_dot(utt, k, a2, a1, a2x, a1x, nu, de);
         nu = wave_sum(nu);
         de = wave_sum(de);
         hn[k] = k < a.K ? hs[k] * __builtin_amdgcn_sqrtf(nu * fast_rcp(de)) : 0.f;       // mcem.py:121
@@ -427,9 +465,10 @@ __global__ __launch_bounds__(256, VN_HG_WAVES) void hg_stream_kernel(const Strea
 }
 
 template <int NCH, int KP, typename ST>
-__global__ __launch_bounds__(256, VN_WS_WAVES) void wf_stream_kernel(const StreamArgs a) {
+__global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void wf_stream_kernel(const StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
-  FrameCtx<NCH, KP, ST> fc(a, wlds + (size_t)(threadIdx.x >> 6) * a.Fs * KP);
+  FrameCtx<NCH, KP, ST> fc(a, wlds + (KP <= 8 ? (size_t)(threadIdx.x >> 6) * a.Fs * KP : 0));
+  fc.stage_block_w();
   using RBt = RowBatch<NCH, ST>;
   int n_beg, n_end;
   wave_frames(a.NT, n_beg, n_end);
@@ -520,8 +559,18 @@ StreamArgs base_args(const vaenmf_plan* p) {
 enum { SK_WSTATS, SK_HG, SK_WF };
 
 template <int KIND, int NCH, int KP, typename ST>
-void launch_st(const StreamArgs& a, int grid, hipStream_t st) {
-  const size_t lds = KP <= 8 ? (size_t)4 * a.Fs * KP * sizeof(float) : 0;     // one W[utt] per wavefront
+void launch_st(StreamArgs a, int grid, hipStream_t st) {
+  // rank <= 8: one W[utt] per wavefront; above: one per workgroup when it leaves room for two workgroups per CU
+  const size_t one = (size_t)a.Fs * KP * sizeof(float);
+  const size_t lds = KP <= 8 ? 4 * one : (one <= 72 * 1024 ? one : 0);
+  a.w_blk_lds = KP > 8 && lds > 0;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)wstats_stream_kernel<NCH, KP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)hg_stream_kernel<NCH, KP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)wf_stream_kernel<NCH, KP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr_done = true;
+  }
   if (KIND == SK_WSTATS) hipLaunchKernelGGL((wstats_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
   else if (KIND == SK_HG) hipLaunchKernelGGL((hg_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
   else hipLaunchKernelGGL((wf_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
