@@ -630,13 +630,13 @@ def test_stored_m_step_and_wiener_match_the_decoding_ones(F, K, prec):
     H0 = [np.maximum(g.random((K, n)), 1e-8).astype(np.float32) for n in counts]
 
     def prep():
-        eng = make_engine(params, F, K, counts, Rcap=27, seeds=seeds, precision=prec)
+        eng = make_engine(params, F, K, counts, Rcap=40, seeds=seeds, precision=prec)
         eng.set_spectrogram(Xs)
         eng.init_nmf(W0, H0)
         eng.sample_store(True)
         return eng
 
-    for (ns, bi) in ((10, 6), (7, 0), (27, 3)):
+    for (ns, bi) in ((10, 6), (7, 0), (27, 3), (40, 2)):     # 40 samples: more than one register batch of rows
         ea, eb = prep(), prep()
         for it in range(2):
             for e in (ea, eb):
