@@ -189,9 +189,9 @@ struct FrameCtx {
 // the batch is issued before the first use, so a wavefront keeps RB x 0.5-1 KiB in flight -- the kernels are
 // latency-bound otherwise (86 % of the wave time in s_waitcnt with 4 loads in flight) -- and the H / g / cost
 // passes of hg_stream reuse the registers instead of reading the rows again when the frame fits one batch.
-template <int NCH, typename ST>
+template <int NCH, typename ST, int DIV = 1>
 struct RowBatch {
-  static constexpr int RB = (sizeof(ST) == 2 ? 32 : 16) / NCH;
+  static constexpr int RB = (sizeof(ST) == 2 ? 32 : 16) / NCH / DIV;
   using raw_t = typename std::conditional<sizeof(ST) == 4, f32x4, bf16x4>::type;
   raw_t raw[RB][NCH];
   float xr;                    // lane j: extra bin (F-1) of row j of the batch
@@ -238,6 +238,69 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void 
   using RBt = RowBatch<NCH, ST>;
   int n_beg, n_end;
   wave_frames(a.NT, n_beg, n_end);
+  if (a.R <= RBt::RB) {
+    // The frame fits one batch: two half batches, each refilled with the NEXT frame's rows as soon as it has been
+    // consumed, so that half a frame of loads is in flight while the other half is computed.
+    using Half = RowBatch<NCH, ST, 2>;
+    constexpr int HB = Half::RB;
+    Half h0, h1;
+    auto base_of = [&](int n) { return reinterpret_cast<const ST*>(a.VsS) + (size_t)n * a.Rs * a.Fs; };
+    const int R0 = a.R < HB ? a.R : HB;              // rows of the first half
+    if (n_beg < n_end) {
+      h0.load(fc, base_of(n_beg), a.src + n_beg, 0, R0);
+      if (a.R > HB) h1.load(fc, base_of(n_beg), a.src + n_beg, HB, a.R); else h1.nr = 0, h1.xr = 0.f;
+    }
+    for (int n = n_beg; n < n_end; ++n) {
+      const int utt = a.frame_utt[n];
+      fc.set_utt(utt);
+      const float gn = a.g[n];
+      float h[KP];
+#pragma unroll
+      for (int k = 0; k < KP; k += 4) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h[k + t] = hv[t];
+      }
+      f32x4 vb[NCH], x2[NCH], a1[NCH], a2[NCH];
+      float vbx, x2x, a1x = 0.f, a2x = 0.f;
+      fc.noise_var(utt, h, vb, vbx);
+      fc.load_x2(n, x2, x2x);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) a1[c] = a2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto consume = [&](const Half& hb) {
+#pragma unroll
+        for (int r = 0; r < HB; ++r)
+          if (r < hb.nr) {
+            f32x4 v[NCH];
+            hb.get(r, v);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
+                a1[c][t] += q;
+                a2[c][t] += q * q;
+              }
+          }
+        const float q = fast_rcp(gn * hb.xr + vbx) * hb.xmask(fc);
+        a1x += wave_sum(q);
+        a2x += wave_sum(q * q);
+      };
+      consume(h0);
+      if (n + 1 < n_end) h0.load(fc, base_of(n + 1), a.src + n + 1, 0, R0);
+      if (a.R > HB) {
+        consume(h1);
+        if (n + 1 < n_end) h1.load(fc, base_of(n + 1), a.src + n + 1, HB, a.R);
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a2[c][t] *= x2[c][t];
+      fc.store_row(a.A1 + (size_t)n * a.Fs, a1, a1x);
+      fc.store_row(a.P + (size_t)n * a.Fs, a2, a2x * x2x);
+    }
+    return;
+  }
   for (int n = n_beg; n < n_end; ++n) {
     const ST* base = reinterpret_cast<const ST*>(a.VsS) + (size_t)n * a.Rs * a.Fs;
     const int32_t* srow = a.src + n;
