@@ -197,3 +197,30 @@ def test_wav_io_and_speech_list(tmp_path):
     assert speech_list(root, "train") == ["CSR-1-WSJ-0/WAV/wsj0/si_tr_s/011/011a010a.wav"]
     wavio.write(root + "clip.wav", np.array([2.0, -2.0, 0.5]), 16000)
     assert list((wavio.read(root + "clip.wav")[0] * 32768).astype(int)) == [32767, -32768, 16384]
+
+
+def test_nist_sphere_reader(tmp_path):
+    """Raw WSJ0 files are NIST SPHERE (1024-byte ASCII header, then 16-bit PCM): the header layout is the one of the
+    reference-committed data/subset/raw/.../440c020a.wav (sample_count 138583, sample_min -7385, sample_max 4084,
+    sample_byte_format 01, sample_coding pcm -- checked against that file when the fixture was written); both byte
+    orders, refusal of compressed payloads."""
+    from vaenmf import wavio
+    z = np.load(GOLDEN + "/metrics_dummy_m2.npz")
+    pcm = z["a_s"][:7001].astype(np.int16)
+
+    def sphere(order, coding="pcm"):
+        lines = ["NIST_1A", "   1024", "database_id -s4 wsj0", "channel_count -i 1", "sample_count -i %d" % len(pcm),
+                 "sample_min -i %d" % pcm.min(), "sample_max -i %d" % pcm.max(), "sample_rate -i 16000", "sample_n_bytes -i 2",
+                 "sample_byte_format -s2 %s" % order, "sample_sig_bits -i 16", "sample_coding -s%d %s" % (len(coding), coding), "end_head"]
+        hdr = ("\n".join(lines) + "\n").encode("ascii")
+        return hdr + b" " * (1024 - len(hdr)) + pcm.astype("<i2" if order == "01" else ">i2").tobytes()
+
+    for order in ("01", "10"):
+        p = str(tmp_path / ("s%s.wav" % order))
+        open(p, "wb").write(sphere(order))
+        x, fs = wavio.read(p)
+        assert fs == 16000 and x.dtype == np.float64 and np.array_equal(x * 32768.0, pcm.astype(np.float64))
+    p = str(tmp_path / "shorten.wav")
+    open(p, "wb").write(sphere("01", "pcm,embedded-shorten-v2.00"))
+    with pytest.raises(NotImplementedError):
+        wavio.read(p)
