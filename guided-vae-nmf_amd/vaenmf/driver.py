@@ -7,6 +7,9 @@ scripts/evaluate_M2_vad.py (process_utt / process_sublist / main), batched.
   sharding      np.array_split(file_paths, world_size)[rank]               (evaluate_M1.py:203-206)
   per utterance read <processed>/<rel>_x.wav, STFT, MCEM, iSTFT with max_len = T_orig,
                 write <output>/<rel>_s_est.wav and _n_est.wav             (evaluate_M1.py:114-166)
+  M2            with a classifier, the soft and hard labels of every utterance are saved as
+                '<rel> _ibm_soft_est.pt' (sic: the reference's file name has the blank) and
+                '<rel>_ibm_hard_est.pt', (frames, label dim) tensors      (evaluate_M2_vad.py:165-166)
 Utterances of different length are batched together (ragged frame counts)."""
 import glob
 import os
@@ -45,10 +48,14 @@ def evaluate(rec: Reconstructor, file_paths, processed_data_dir, output_data_dir
         s_hat, n_hat, _ = rec.enhance(wav, counts, seeds=seeds, init_seed=seed + b0, classifier=classifier, mean=mean, std=std)
         s_hat, n_hat = s_hat.cpu().numpy(), n_hat.cpu().numpy()
         off = np.concatenate([[0], np.cumsum(counts)])
+        foff = np.concatenate([[0], np.cumsum(rec.frame_counts)])
         for i, fp in enumerate(files):
             out = os.path.splitext(output_data_dir + fp)[0]
             os.makedirs(os.path.dirname(out), exist_ok=True)
             wavio.write(out + "_s_est.wav", s_hat[off[i]:off[i + 1]], rec.fs)
             wavio.write(out + "_n_est.wav", n_hat[off[i]:off[i + 1]], rec.fs)
+            if classifier is not None:
+                torch.save(rec.y_soft[foff[i]:foff[i + 1]].cpu(), out + " _ibm_soft_est.pt")
+                torch.save(rec.y_hard[foff[i]:foff[i + 1]].cpu(), out + "_ibm_hard_est.pt")
             written.append((out + "_s_est.wav", out + "_n_est.wav"))
     return written

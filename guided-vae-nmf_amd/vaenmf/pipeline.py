@@ -55,6 +55,7 @@ class Reconstructor:
         eng.g.fill_(1.0)
         if classifier is not None:
             self.y_soft, y = eng.classify(classifier, mean, std, self.eps)
+            self.y_hard = y
         if y is not None:
             eng.set_labels(y)
         eng.encode(self.enc, y)

@@ -459,6 +459,21 @@ def test_file_driver_ragged_batch(tmp_path):
         assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
     # same utterance seed => identical result whatever the batch composition (first file: same seed in both runs)
     assert np.array_equal(wavio.read(w_all[0][0])[0], wavio.read(w_one[0][0])[0])
+    # M2 (VAD-guided, bf16 mode with the sample store): the driver also dumps the classifier's labels per utterance
+    # under the reference's file names (evaluate_M2_vad.py:165-166; the blank in the soft file's name is the reference's)
+    p2 = orc.xavier_normal_params([513, 32, [128, 128]], seed=1, y_dim=1)
+    cp = orc.xavier_normal_classifier([513, [128, 128], 1], seed=2)
+    clf = [(cp["hidden.0.weight"], cp["hidden.0.bias"]), (cp["hidden.1.weight"], cp["hidden.1.bias"]),
+           (cp["output_layer.weight"], cp["output_layer.bias"])]
+    rec2 = Reconstructor(p2, 513, 10, niter=2, model="M2", fs=16000, wlen_sec=64e-3, precision="bf16", max_frames=400, max_utts=4)
+    w2 = evaluate(rec2, files, proc, out + "m2/", batch_size=8, classifier=clf)
+    for (sa, na), name in zip(w2, sorted(lens)):
+        stem = sa[:-len("_s_est.wav")]
+        soft = torch.load(stem + " _ibm_soft_est.pt", weights_only=True)
+        hard = torch.load(stem + "_ibm_hard_est.pt", weights_only=True)
+        nfr = 1 + (lens[name] + (256 if lens[name] % 256 else 0)) // 256
+        assert soft.shape == hard.shape == (nfr, 1) and torch.equal(hard, (soft > 0.5).float())
+        assert len(wavio.read(sa)[0]) == lens[name] and np.all(np.isfinite(wavio.read(sa)[0]))
 
 
 def test_nonmf_variant_against_reference():
