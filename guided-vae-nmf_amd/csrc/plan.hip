@@ -97,7 +97,6 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   p->have_weights = false;
   p->Vb_ext = nullptr;
   p->store_on = false; p->VsS = nullptr; p->src = nullptr; p->VsS_cap = p->src_cap = 0; p->store_R = p->store_Rs = 0;
-  if (const char* sv = getenv("VAENMF_STORE")) p->store_on = sv[0] == '1';   // dev override (A/B runs)
   p->n_utt = p->NT = p->n_tiles = 0;
   p->prof_on = false;
   p->prof_used = 0;

@@ -163,19 +163,6 @@ struct FrameCtx {
       x2[c] = cv[c] ? *reinterpret_cast<const f32x4*>(a.X2 + (size_t)n * a.Fs + f0[c]) : f32x4{0.f, 0.f, 0.f, 0.f};
     x2x = has_x ? a.X2[(size_t)n * a.Fs + a.F - 1] : 0.f;
   }
-  // variances of sample r of frame n (row of the store), this lane's bins; lanes without bins read a valid dummy
-  __device__ __forceinline__ void load_vs(const ST* row, f32x4 (&v)[NCH], float& vx) const {
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      if (sizeof(ST) == 4) {
-        v[c] = *reinterpret_cast<const f32x4*>(row + (cv[c] ? f0[c] : 0));
-      } else {
-        const bf16x4 b = *reinterpret_cast<const bf16x4*>(row + (cv[c] ? f0[c] : 0));
-        v[c] = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-      }
-    }
-    vx = (float)row[has_x ? a.F - 1 : 0];
-  }
   // write a per-bin result row (bins >= F zeroed)
   __device__ __forceinline__ void store_row(float* dst, const f32x4 (&v)[NCH], float vx) const {
 #pragma unroll
@@ -655,9 +642,7 @@ template <int KIND>
 int launch_stream(const vaenmf_plan* p, const StreamArgs& a, hipStream_t st) {
   const int nch = (p->Fm + 255) / 256;
   // enough wavefronts in flight to cover the HBM latency: 4 per SIMD, blocks of 4 wavefronts
-  int mult = 8;      // (finer than the resident wave count: the last round of blocks stays balanced)
-  if (const char* e = getenv("VAENMF_SGRID")) mult = atoi(e) > 0 ? atoi(e) : 8;      // dev override (A/B runs)
-  int grid = p->n_sms * mult;
+  int grid = p->n_sms * 8;      // (finer than the resident wave count: the last round of blocks stays balanced)
   if (grid * 4 > p->NT) grid = (p->NT + 3) / 4;
   if (nch <= 1) launch_kp<KIND, 1>(a, p->Kp, grid, st);
   else if (nch == 2) launch_kp<KIND, 2>(a, p->Kp, grid, st);
