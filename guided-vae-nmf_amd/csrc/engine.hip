@@ -470,7 +470,8 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
   int cur_src[2] = {a.nsamples, a.nsamples};
   if (STORE) {
 #pragma unroll
-    for (int fg = 0; fg < 2; ++fg) voff[fg] = (uint32_t)(fvalid[fg] ? nrow[fg] : a.NT) * (uint32_t)(a.Rs * a.Fs) + 4u * q;
+    for (int fg = 0; fg < 2; ++fg)      // BYTE offset (the host keeps the store below 4 GB)
+      voff[fg] = ((uint32_t)(fvalid[fg] ? nrow[fg] : a.NT) * (uint32_t)(a.Rs * a.Fs) + 4u * q) * (uint32_t)sizeof(store_t);
   }
   // ---- noise streams: thread of the team <-> (frame of the team, latent quad); 256 streams
   const int sid = threadIdx.x - d.team * NW * 64, sfr = sid >> 3, squad = sid & 7;
@@ -509,8 +510,8 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
   // next_step: the MH step whose noise is drawn during this evaluation (>= S: none); slot: store slot (DOST)
   auto energy = [&](const float (&zz)[2][8], double (&E)[2], int next_step, int slot, auto dost) {
     constexpr bool DOST = STORE && decltype(dost)::value;
-    store_t* const vbase = reinterpret_cast<store_t*>(a.VsS);
-    const uint32_t soff = DOST ? (uint32_t)(slot * a.Fs) : 0u;
+    // uniform base (+ slot, SGPR) + 32-bit per-lane byte offset + the tile's constant: no 64-bit VALU address math
+    char* const vbase = reinterpret_cast<char*>(a.VsS) + (DOST ? (size_t)slot * a.Fs * sizeof(store_t) : 0);
     bf16x8 zhi[2], zlo[2];
     split8<SPLIT>(zz[0], zhi[0], zlo[0]);
     split8<SPLIT>(zz[1], zhi[1], zlo[1]);
@@ -538,9 +539,16 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
               px += (x2[i][fg][t] * v1 + x2[i][fg][t + 1] * v0) * fast_rcp(pp);
             }
             if (DOST) {
-              store_t* dst = vbase + (voff[fg] + (soff + 16u * (uint32_t)(w + NW * i)));
-              if (SPLIT) *reinterpret_cast<f32x4*>(dst) = ev;
-              else *reinterpret_cast<bf16x4*>(dst) = bf16x4{(__bf16)ev[0], (__bf16)ev[1], (__bf16)ev[2], (__bf16)ev[3]};
+              // SGPR base + 32-bit VGPR offset form of the store, written out: the compiler builds a 64-bit VGPR
+              // address per store otherwise (3 VALU instructions each, 8 stores per step)
+              const char* tb = vbase + 16 * (w + NW * i) * sizeof(store_t);
+              if (SPLIT) {
+                // (a store of more than 8 bytes needs 2 wait states before its data registers are overwritten)
+                asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(voff[fg]), "v"(ev), "s"(tb) : "memory");
+              } else {
+                const bf16x4 pk = bf16x4{(__bf16)ev[0], (__bf16)ev[1], (__bf16)ev[2], (__bf16)ev[3]};
+                asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(voff[fg]), "v"(pk), "s"(tb) : "memory");
+              }
             }
             e[fg] += (double)(pl * LN2_F + px);
           }
@@ -556,7 +564,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
         if (DOST && w == 2 && q == 0) {      // (the per-step bookkeeping stores are spread over the waves of the team)
           // the whole 16-bin tail of the row (the bin and its zero padding) in full 32-byte sectors: a lone 2- or
           // 4-byte store per frame and step is a read-modify-write in the memory system (measured: 5 % of the launch)
-          store_t* dst = vbase + (voff[fg] + (soff + (uint32_t)dw.Fm));
+          store_t* dst = reinterpret_cast<store_t*>(vbase + (size_t)dw.Fm * sizeof(store_t) + voff[fg]);
           if (SPLIT) {
             *reinterpret_cast<f32x4*>(dst) = f32x4{vs, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1401,8 +1409,8 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
     const int Rs = nsamples + 1;
     const size_t esz = split ? sizeof(float) : sizeof(__bf16);
     const size_t need_v = (size_t)(p->NT + 1) * Rs * p->Fs * esz, need_s = (size_t)p->NT * Rs;   // + a spare block (idle lanes)
-    VN_REQUIRE((size_t)(p->NT + 1) * Rs * p->Fs < (1ull << 32), "sample store: %d frames x %d slots x %d bins exceeds the 32-bit "
-               "element offsets of the chain kernel; bind a smaller batch or switch the store off", p->NT, Rs, p->Fs);
+    VN_REQUIRE(need_v < (1ull << 32), "sample store: %d frames x %d slots x %d bins exceeds the 32-bit byte offsets of "
+               "the chain kernel; bind a smaller batch or switch the store off", p->NT, Rs, p->Fs);
     if (need_v > p->VsS_cap) {
       if (p->VsS) VN_CHECK_HIP(hipFree(p->VsS));
       p->VsS = nullptr; p->VsS_cap = 0;
@@ -1521,7 +1529,7 @@ extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* H
   // with the sample store on (vaenmf_sample_store), the chain leaves the samples' variances in HBM and the
   // M-step / Wiener filter stream them; otherwise they decode Zs again
   // (a batch too large for the store's 32-bit element offsets, or for the streaming kernels' bin range, decodes)
-  auto fits = [&](int ns) { return (size_t)(p->NT + 1) * (ns + 1) * p->Fs < (1ull << 32) && p->Fm <= 768; };
+  auto fits = [&](int ns) { return (size_t)(p->NT + 1) * (ns + 1) * p->Fs * 4 < (1ull << 32) && p->Fm <= 768; };
   const bool want = p->store_on, stored = want && fits(nsE) && fits(nsWF);
   p->store_on = stored;
   struct Restore { vaenmf_plan* p; bool v; ~Restore() { p->store_on = v; } } restore{p, want};
