@@ -40,18 +40,20 @@ def test_si_sdr_and_cost_distribution_match_oracle():
     to_dev = lambda i: torch.from_numpy(np.concatenate([sg[i] for sg in sig]).astype(np.float32)).to(dev)
     wav_x, wav_s, wav_n = to_dev(2), to_dev(0), to_dev(1)
     res = {}
-    for prec in ("bf16x3", "bf16"):
+    # "bf16": the bench path (sample-variance store with bf16 rows feeding the M-step); "bf16 decode": the same
+    # precision with the M-step decoding the samples again
+    for name, prec, store in (("bf16x3", "bf16x3", None), ("bf16", "bf16", None), ("bf16 decode", "bf16", False)):
         rec = Reconstructor(params, F, K, niter=NITER, fs=FS, wlen_sec=WLEN, precision=prec, device=dev,
-                            max_frames=UTTS * 120, max_utts=UTTS)
+                            max_frames=UTTS * 120, max_utts=UTTS, store=store)
         out = []
         for sd in range(SEEDS):
             s_hat, n_hat, cost = rec.enhance(wav_x, [T] * UTTS, seeds=[1000 * sd + u for u in range(UTTS)], init_seed=sd)
             G = vm.gram3_batch(s_hat, wav_s, wav_n, [T] * UTTS)
             out.append(np.stack([vm.ratios_from_gram(G)[0], cost[:, -1].cpu().numpy()], 1))
-        res[prec] = np.stack(out, 1)                       # [U, SEEDS, 2]
+        res[name] = np.stack(out, 1)                       # [U, SEEDS, 2]
     sem = ref[:, :, 0].std(1, ddof=1).mean() / np.sqrt(UTTS * SEEDS)
     csem = ref[:, :, 1].std(1, ddof=1) / np.abs(ref[:, :, 1].mean(1)) * np.sqrt(2.0 / SEEDS)   # rel. s.e. of a difference of means
-    for prec, ctol in (("bf16x3", 2e-3), ("bf16", 1e-2)):
+    for prec, ctol in (("bf16x3", 2e-3), ("bf16", 1e-2), ("bf16 decode", 1e-2)):
         d_sdr = res[prec][:, :, 0].mean() - ref[:, :, 0].mean()
         d_cost = np.abs(res[prec][:, :, 1].mean(1) / ref[:, :, 1].mean(1) - 1)
         print("%s: mean SI-SDR gpu %.3f dB, oracle %.3f dB (diff %.3f, oracle seed sem %.3f); rel cost diff per utt %s (seed s.e. %s)"
