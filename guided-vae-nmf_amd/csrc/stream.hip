@@ -642,10 +642,10 @@ template <int KIND>
 int launch_stream(const vaenmf_plan* p, const StreamArgs& a, hipStream_t st) {
   const int nch = (p->Fm + 255) / 256;
   // enough wavefronts in flight to cover the HBM latency: 4 per SIMD, blocks of 4 wavefronts
-  // H/g, Wiener: finer than the resident wave count, so that the last round of blocks stays balanced; W-stats
-  // pipelines its loads across the frames of a wavefront: exactly the resident count (4 per SIMD), longer runs
-  // (measured 4: 0.169 ms, 6: 0.220, 8: 0.179, 12: 0.192)
-  int grid = p->n_sms * (KIND == SK_WSTATS ? 4 : 8);
+  // exactly one resident set of wavefronts (4 per SIMD at rank 8): the W-statistics kernel pipelines its loads
+  // across the frames of a wavefront and wants long runs (blocks per CU 4: 0.169 ms, 6: 0.220, 8: 0.179, 12: 0.192);
+  // H/g is indifferent (4: 0.287, 8: 0.291, 16: 0.305)
+  int grid = p->n_sms * 4;
   if (grid * 4 > p->NT) grid = (p->NT + 3) / 4;
   if (nch <= 1) launch_kp<KIND, 1>(a, p->Kp, grid, st);
   else if (nch == 2) launch_kp<KIND, 2>(a, p->Kp, grid, st);
