@@ -81,6 +81,7 @@ def main():
                     help="decoder MFMA mode: bf16 (BASELINE config 2) or bf16x3 (3-term split, ~fp32 accuracy)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra bf16x3 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-store", action="store_true", help="sample store also in bf16x3 mode (float rows)")
     ap.add_argument("--no-store", action="store_true",
                     help="M-step / Wiener filter decode the samples again instead of streaming the chain's stored variances")
     ap.add_argument("--model", default="M1", choices=["M1", "M2vad", "M2ibm"],
@@ -128,7 +129,7 @@ def main():
                (cp["output_layer.weight"], cp["output_layer.bias"])]
     rec = Reconstructor(params, F, args.rank_k, niter=args.niter, model="M1" if not Dy else "M2", reference_compat=True, fs=fs,
                         wlen_sec=wlen, precision=args.precision, device=dev, max_frames=U * 520, max_utts=U,
-                        store=False if args.no_store else None)
+                        store=False if args.no_store else (True if args.force_store else None))
     nsE, biE, nsW, biW = rec.nsE, rec.biE, rec.nsW, rec.biW
 
     def step(i):
