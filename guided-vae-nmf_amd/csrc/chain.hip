@@ -1,0 +1,496 @@
+// Wave-private Metropolis-Hastings chains (MCEM_M1.sample_posterior mcem.py:371-441, MCEM_M2 :218-294).
+//
+// One wavefront owns 16 frames for a whole chain and evaluates the complete decoder
+// (python/models/models.py:118-121) for them on v_mfma_f32_16x16x32_bf16: the frames are the MFMA column
+// dimension, every feature tile of every layer belongs to the same wavefront.  An accumulator tile
+// (lane (q,c): features 4q..4q+3 of frame c) is, after tanh and the bf16 rounding, exactly half of the
+// B fragment of the next layer IN THE SAME LANE (k-permutation phi(s,q,j) = 32 s + 16 (j>>2) + 4 q + (j&3),
+// applied to the weights on the host, plan.hip: pack_weights), so activations never leave the registers:
+// no LDS exchange, no barrier anywhere in the chain.  The sum over bins of the acceptance ratio is in-lane
+// plus two permlane swaps, the noise of a frame's 32 latents is drawn by the four lanes that hold them, and
+// the wavefronts of a workgroup share nothing but the LDS-resident weights: two wavefronts on a SIMD drift
+// apart and fill each other's MFMA / transcendental latencies.
+//
+// Bin order of the last layer (bf16 mode): tiles are paired so that a lane holds 8 CONSECUTIVE bins per
+// pair (bin = 32 (t>>1) + 8 q + 4 (t&1) + j) and writes its part of a sample-variance row with 16-byte
+// stores that cover 64 contiguous bytes per frame and instruction; the bf16x3 mode stores float rows and
+// keeps the natural order (bin = 16 t + 4 q + j).  The permutation is applied to W3 / b3 on the host.
+#include "common.h"
+
+#ifndef VN_SB
+#define VN_SB __builtin_amdgcn_sched_barrier(0)
+#endif
+
+namespace {
+
+constexpr int NK = HID / 32;      // k-steps over a hidden layer
+constexpr int NTH = HID / 16;     // feature tiles of a hidden layer
+constexpr int WT_FRAMES = 16;     // frames per wavefront
+#ifndef VN_WC_WAVES_BF16
+#define VN_WC_WAVES_BF16 8
+#endif
+
+struct WcArgs {
+  const __bf16 *w1f, *w2f, *w3f;   // fragment order [tile][kstep][part hi/lo][lane][8]; w3f in the chain's bin order
+  const float *b1, *b2, *b3;       // b3 in the chain's bin order, padded to 16 NT3 with -200 (2^-200 = 0: padding bins store exact zeros)
+  int NT3;                         // bin tiles (the last one may be partial)
+  int Tm;                          // tiles in paired order (bf16 mode); the rest is natural
+  int F, Fs;
+  const float *X2, *W, *Ht, *g, *B1, *Vb;
+  float *Z, *Zs, *acc_out;
+  void* VsS;                       // sample-variance store [NT+1][Rs][Fs] (float: bf16x3 mode, bf16: bf16 mode) or null
+  unsigned VsS_bytes;
+  int32_t* src;                    // [Rs][NT]
+  int Rs;
+  const int32_t *wt_utt, *wt_n0, *wt_cnt;   // wave tiles: <= 16 frames of one utterance
+  int n_wtiles;
+  const int32_t* frame_off;
+  const uint64_t* utt_seed;
+  const float *eps, *u;            // replay draws or null
+  int Kp, NT, Rcap, nsamples, burnin, rng_mode, update_Z;
+  int n_hi_lds;                    // W3 tiles whose hi fragments are in LDS (the rest streams from L2)
+  uint32_t call;
+  float sd;
+};
+
+template <bool SPLIT>
+struct WcLds {
+  static constexpr int PARTS = SPLIT ? 2 : 1;
+  static constexpr int W1 = 0;                                  // [8][PARTS][1 KB]
+  static constexpr int W2 = W1 + NTH * PARTS * 1024;            // [8][4][PARTS][1 KB]
+  static constexpr int B1 = W2 + NTH * NK * PARTS * 1024;       // float[128]
+  static constexpr int B2 = B1 + HID * 4;
+  static constexpr int B3 = B2 + HID * 4;                       // float[16 * 40]
+  static constexpr int W3 = B3 + 640 * 4;                       // hi blocks [tile][kstep][1 KB] of the first n_hi_lds tiles,
+                                                                // then (LOL) the lo blocks of all tiles
+  static constexpr int fixed_bytes = W3;
+};
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ unsigned pk2(float a, float b) { return __builtin_bit_cast(unsigned, bf16x2{(__bf16)a, (__bf16)b}); }   // v_cvt_pk_bf16_f32
+__device__ __forceinline__ float bf_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
+__device__ __forceinline__ bf16x8 cat8(const bf16x4 a, const bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+template <bool SPLIT>
+__device__ __forceinline__ void pack4(const f32x4 h, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const __bf16 x = (__bf16)h[t];
+    hi[t] = x;
+    lo[t] = SPLIT ? (__bf16)(h[t] - (float)x) : (__bf16)0.f;
+  }
+}
+__device__ __forceinline__ f32x4 tanh4(const f32x4 a) {
+  f32x4 h;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) h[t] = fast_tanh(a[t]);
+  return h;
+}
+template <bool SPLIT>
+__device__ __forceinline__ f32x4 mma(const bf16x8 whi, const bf16x8 wlo, const bf16x8 ahi, const bf16x8 alo, f32x4 acc) {
+  if (SPLIT) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ahi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, alo, acc, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, ahi, acc, 0, 0, 0);
+}
+
+// MAXT : compile-time bound of the bin tiles; EXACT: NT3 == MAXT (no per-tile checks)
+// LOL  : the lo fragments of W3 are in LDS too (bf16x3 mode, small F); otherwise they stream from L2
+// HIALL: every hi fragment of W3 is in LDS
+// M2   : per-frame layer-1 bias B1 = b1 + W1[:, L:] y_n (kept in registers), else b1 from LDS
+template <int MAXT, bool EXACT, bool SPLIT, bool STORE, int NWAVES, bool LOL, bool HIALL, bool M2>
+__global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const WcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = WcLds<SPLIT>;
+  constexpr int PARTS = L::PARTS;
+  using store_t = typename std::conditional<SPLIT, float, __bf16>::type;
+  const int NT3 = EXACT ? MAXT : a.NT3;
+  const int n_hi = HIALL ? NT3 : a.n_hi_lds;
+
+  // ---- workgroup prologue: weights and biases into LDS (the only barrier of the kernel)
+  {
+    const int nthr = NWAVES * 64;
+    auto stage = [&](char* dst, const __bf16* srcp, int nblk) {    // blocks [blk][2 parts] -> [blk][PARTS]
+      for (int e = threadIdx.x; e < nblk * PARTS * 64; e += nthr) {
+        const int chunk = e & 63, pb = e >> 6, b = pb / PARTS, part = pb - b * PARTS;
+        *reinterpret_cast<f32x4*>(dst + (size_t)e * 16) =
+            *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(srcp) + ((size_t)(b * 2 + part) * 64 + chunk) * 16);
+      }
+    };
+    stage(smem + L::W1, a.w1f, NTH);
+    stage(smem + L::W2, a.w2f, NTH * NK);
+    for (int e = threadIdx.x; e < n_hi * NK * 64; e += nthr) {      // hi blocks of W3
+      const int chunk = e & 63, b = e >> 6;
+      *reinterpret_cast<f32x4*>(smem + L::W3 + (size_t)e * 16) =
+          *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.w3f) + ((size_t)(b * 2) * 64 + chunk) * 16);
+    }
+    if (SPLIT && LOL)
+      for (int e = threadIdx.x; e < NT3 * NK * 64; e += nthr) {     // lo blocks of W3, behind the hi blocks
+        const int chunk = e & 63, b = e >> 6;
+        *reinterpret_cast<f32x4*>(smem + L::W3 + (size_t)n_hi * NK * 1024 + (size_t)e * 16) =
+            *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.w3f) + ((size_t)(b * 2 + 1) * 64 + chunk) * 16);
+      }
+    float* b1s = reinterpret_cast<float*>(smem + L::B1);
+    float* b2s = reinterpret_cast<float*>(smem + L::B2);
+    float* b3s = reinterpret_cast<float*>(smem + L::B3);
+    for (int i = threadIdx.x; i < HID; i += nthr) { b1s[i] = a.b1[i]; b2s[i] = a.b2[i]; }
+    for (int i = threadIdx.x; i < 16 * NT3; i += nthr) b3s[i] = a.b3[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
+  const unsigned l16 = (unsigned)lane * 16u;
+  const float* b1l = reinterpret_cast<const float*>(smem + L::B1);
+  const float* b2l = reinterpret_cast<const float*>(smem + L::B2);
+  const float* b3l = reinterpret_cast<const float*>(smem + L::B3);
+  const char* w3lo_lds = smem + L::W3 + (size_t)n_hi * NK * 1024;
+  const char* w3g = reinterpret_cast<const char*>(a.w3f);
+  const int S = a.nsamples + a.burnin;
+  // first of this lane's 4 consecutive bins in tile t
+  const int Tm = EXACT ? ((MAXT - 1) & ~1) : a.Tm;
+  auto bin0 = [&](int t) { return (!SPLIT && t < Tm) ? 32 * (t >> 1) + 8 * q + 4 * (t & 1) : 16 * t + 4 * q; };
+  auto tile_on = [&](int t) { return EXACT || t < NT3; };
+  auto tile_on3 = [&](int n, int t) { return n != MAXT || EXACT || t < NT3; };      // (hidden layers: every tile)
+
+  __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(a.VsS, 0, STORE ? (int)a.VsS_bytes : 0, 0x00020000);
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int wt = blockIdx.x * NWAVES + wave; wt < a.n_wtiles; wt += gridDim.x * NWAVES) {
+    const int utt = a.wt_utt[wt], n0 = a.wt_n0[wt], cnt = a.wt_cnt[wt];
+    const bool fvalid = c < cnt;
+    const int nrow = n0 + (fvalid ? c : cnt - 1);          // idle lanes shadow the last frame (no stores)
+    const float gn = a.g[nrow];
+    // ---- per-(bin, frame) constants in accumulator layout: X2 and Vb = W H (mcem.py:81-82) or the given noise PSD.
+    // Padding bins: X2 = 0, Vb = 1 and (b3 = -200, W3 = 0) Vs = 0, so their term is exactly 0.
+    f32x4 x2[MAXT], vb[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      x2[t] = f32x4{0, 0, 0, 0};
+      vb[t] = f32x4{1, 1, 1, 1};
+      if (tile_on(t)) {
+        const int f0 = bin0(t);
+        f32x4 xv = *reinterpret_cast<const f32x4*>(a.X2 + (size_t)nrow * a.Fs + f0);
+        f32x4 v = {0, 0, 0, 0};
+        if (a.Vb) {
+          v = *reinterpret_cast<const f32x4*>(a.Vb + (size_t)nrow * a.Fs + f0);
+        } else {
+          for (int k = 0; k < a.Kp; k += 4) {              // (once per launch: a plain loop, operands from L1/L2)
+            const f32x4 h4 = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)nrow * a.Kp + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + f0 + j) * a.Kp + k);
+              v[j] += w4[0] * h4[0] + w4[1] * h4[1] + w4[2] * h4[2] + w4[3] * h4[3];
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (f0 + j >= a.F) { xv[j] = 0.f; v[j] = 1.f; }
+        x2[t] = xv;
+        vb[t] = v;
+      }
+    }
+    f32x4 b1r[M2 ? NTH : 1];                               // M2: layer-1 accumulator init of this lane's frame
+    if (M2) {
+#pragma unroll
+      for (int t = 0; t < NTH; ++t) b1r[M2 ? t : 0] = *reinterpret_cast<const f32x4*>(a.B1 + (size_t)nrow * HID + 16 * t + 4 * q);
+    }
+    // ---- current latent state, fragment order: latents 4q..4q+3 and 16+4q..16+4q+3 of frame c
+    float z[8];
+    {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(a.Z + (size_t)nrow * LAT + 4 * q);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(a.Z + (size_t)nrow * LAT + 16 + 4 * q);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { z[t] = lo[t]; z[4 + t] = hi[t]; }
+    }
+    // ---- sample-variance store: slot r of the frame holds the variances of the proposal of post-burn-in step r,
+    // slot R the state the chain is in when the burn-in ends; src[r][frame] names the slot of the state after
+    // step r (mcem.py:429-437).  Lanes without a frame write to the spare frame block behind the last one.
+    const unsigned fbase = STORE ? (unsigned)(fvalid ? nrow : a.NT) * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(store_t) : 0u;
+    int cur_src = a.nsamples;
+    // ---- noise streams: this lane draws latents 4q..4q+3 (stream q) and 16+4q.. (stream 4+q) of its frame;
+    // the streams are keyed by (utterance seed, frame inside the utterance, latent quad, chain call)
+    Xs128 st0, st1;
+    if (a.rng_mode == VAENMF_RNG_DEVICE) {
+      const uint32_t floc = (uint32_t)(nrow - a.frame_off[utt]);
+      st0 = xs_seed(a.utt_seed[utt], floc, (uint32_t)q, a.call);
+      st1 = xs_seed(a.utt_seed[utt], floc, (uint32_t)(4 + q), a.call);
+    }
+
+    // E(z) = sum_f [log Vx + X2 / Vx] of this lane's frame (all lanes of the frame get the sum).  fp64 across
+    // the tiles: the reference sums per-bin DIFFERENCES of two states (mcem.py:415-416); summing each state
+    // separately needs the extra bits.
+    auto energy = [&](const float (&zz)[8], int slot, auto dost) -> double {
+      constexpr bool DOST = STORE && decltype(dost)::value;
+      // byte offset of this lane's part of the row: frame block + slot + lane part; the tile is the instruction's
+      // immediate offset.  The slot is folded in here and NOT passed as the scalar offset of the buffer store: hipcc
+      // 7.2 leaves out the wait states a store of more than 8 bytes needs before its data registers are rewritten when
+      // the scalar offset is a register (GCNHazardRecognizer assumes no hazard then; gfx950 has it: sporadic garbage
+      // in the first dword of the 16-byte stores).
+      const unsigned voff = DOST ? fbase + (unsigned)slot * (unsigned)a.Fs * (unsigned)sizeof(store_t) : 0u;
+      // B fragments of a layer's input: k-step s <-> feature tiles 2s (elements 0..3) and 2s+1 (elements 4..7)
+      u32x4 bh[NK], bl[NK], ch[NK], cl[NK];
+      auto put = [&](u32x4 (&dh)[NK], u32x4 (&dl)[NK], int t, const f32x4 h) {      // tile t of the next layer's input
+        dh[t >> 1][2 * (t & 1)] = pk2(h[0], h[1]);
+        dh[t >> 1][2 * (t & 1) + 1] = pk2(h[2], h[3]);
+        if (SPLIT) {
+          dl[t >> 1][2 * (t & 1)] = pk2(h[0] - bf_lo(dh[t >> 1][2 * (t & 1)]), h[1] - bf_hi(dh[t >> 1][2 * (t & 1)]));
+          dl[t >> 1][2 * (t & 1) + 1] = pk2(h[2] - bf_lo(dh[t >> 1][2 * (t & 1) + 1]), h[3] - bf_hi(dh[t >> 1][2 * (t & 1) + 1]));
+        }
+      };
+      // One layer, software-pipelined over its output tiles: the weight fragments of tile t+1 are requested, the
+      // MFMAs of tile t issued and the epilogue of tile t-1 computed in the same scheduling region, so a
+      // wavefront covers its own LDS and MFMA latencies with epilogue work.
+      //   NKS k-steps; frag(t, s, hi, lo) loads; bias(t); bop(s, hi, lo) the input fragments; epi(t, acc)
+      auto run_layer = [&](auto nks_c, auto ntiles_c, auto frag, auto bias, auto bop, auto epi) {
+        constexpr int NKS = decltype(nks_c)::value, N = decltype(ntiles_c)::value;
+        bf16x8 wh[2][NKS], wl[2][NKS];
+        f32x4 acc[2];
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) frag(0, s, wh[0][s], wl[0][s]);
+#pragma unroll
+        for (int t = 0; t <= N; ++t) {
+          if (t + 1 < N && tile_on3(N, t + 1)) {
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) frag(t + 1, s, wh[(t + 1) & 1][s], wl[(t + 1) & 1][s]);
+          }
+          if (t < N && tile_on3(N, t)) {
+            f32x4 ac = bias(t);
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+              bf16x8 ah, al;
+              bop(s, ah, al);
+              ac = mma<SPLIT>(wh[t & 1][s], wl[t & 1][s], ah, al, ac);
+            }
+            acc[t & 1] = ac;
+          }
+          if (t > 0 && tile_on3(N, t - 1)) epi(t - 1, acc[(t - 1) & 1]);
+          VN_SB;
+        }
+      };
+      // ---- layer 1: input = the latents of this lane's frame (one k-step)
+      {
+        bh[0][0] = pk2(zz[0], zz[1]); bh[0][1] = pk2(zz[2], zz[3]); bh[0][2] = pk2(zz[4], zz[5]); bh[0][3] = pk2(zz[6], zz[7]);
+        if (SPLIT) {
+          bl[0][0] = pk2(zz[0] - bf_lo(bh[0][0]), zz[1] - bf_hi(bh[0][0]));
+          bl[0][1] = pk2(zz[2] - bf_lo(bh[0][1]), zz[3] - bf_hi(bh[0][1]));
+          bl[0][2] = pk2(zz[4] - bf_lo(bh[0][2]), zz[5] - bf_hi(bh[0][2]));
+          bl[0][3] = pk2(zz[6] - bf_lo(bh[0][3]), zz[7] - bf_hi(bh[0][3]));
+        }
+        run_layer(std::integral_constant<int, 1>{}, std::integral_constant<int, NTH>{},
+                  [&](int t, int, bf16x8& hi, bf16x8& lo) {
+                    const char* p = smem + L::W1 + t * PARTS * 1024 + l16;
+                    hi = *reinterpret_cast<const bf16x8*>(p);
+                    lo = SPLIT ? *reinterpret_cast<const bf16x8*>(p + 1024) : hi;
+                  },
+                  [&](int t) { return M2 ? b1r[M2 ? t : 0] : *reinterpret_cast<const f32x4*>(b1l + 16 * t + 4 * q); },
+                  [&](int, bf16x8& hi, bf16x8& lo) { hi = __builtin_bit_cast(bf16x8, bh[0]); lo = SPLIT ? __builtin_bit_cast(bf16x8, bl[0]) : hi; },
+                  [&](int t, const f32x4 acc) { put(ch, cl, t, tanh4(acc)); });
+      }
+      // ---- layer 2
+      run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, NTH>{},
+                [&](int t, int s, bf16x8& hi, bf16x8& lo) {
+                  const char* p = smem + L::W2 + (t * NK + s) * PARTS * 1024 + l16;
+                  hi = *reinterpret_cast<const bf16x8*>(p);
+                  lo = SPLIT ? *reinterpret_cast<const bf16x8*>(p + 1024) : hi;
+                },
+                [&](int t) { return *reinterpret_cast<const f32x4*>(b2l + 16 * t + 4 * q); },
+                [&](int s, bf16x8& hi, bf16x8& lo) { hi = __builtin_bit_cast(bf16x8, ch[s]); lo = SPLIT ? __builtin_bit_cast(bf16x8, cl[s]) : hi; },
+                [&](int t, const f32x4 acc) { put(bh, bl, t, tanh4(acc)); });
+      // ---- output layer: each finished tile straight into the energy epilogue
+      double e = 0.0;
+      float ef = 0.f;
+      unsigned pk_even0 = 0, pk_even1 = 0;
+      run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, MAXT>{},
+                [&](int t, int s, bf16x8& hi, bf16x8& lo) {
+                  if (HIALL || t < n_hi) hi = *reinterpret_cast<const bf16x8*>(smem + L::W3 + (t * NK + s) * 1024 + l16);
+                  else hi = *reinterpret_cast<const bf16x8*>(w3g + (size_t)((t * NK + s) * 2) * 1024 + l16);
+                  if (!SPLIT) lo = hi;
+                  else if (LOL) lo = *reinterpret_cast<const bf16x8*>(w3lo_lds + (t * NK + s) * 1024 + l16);
+                  else lo = *reinterpret_cast<const bf16x8*>(w3g + (size_t)((t * NK + s) * 2 + 1) * 1024 + l16);
+                },
+                [&](int t) { return *reinterpret_cast<const f32x4*>(b3l + 16 * t + 4 * q); },
+                [&](int s, bf16x8& hi, bf16x8& lo) { hi = __builtin_bit_cast(bf16x8, bh[s]); lo = SPLIT ? __builtin_bit_cast(bf16x8, bl[s]) : hi; },
+                [&](int t, const f32x4 acc) {
+                  // two bins at a time: log Vx0 + log Vx1 = log(Vx0 Vx1), X0/Vx0 + X1/Vx1 = (X0 Vx1 + X1 Vx0)/(Vx0 Vx1)
+                  f32x4 ev;
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) ev[j] = fast_exp(acc[j]);
+                  float pl = 0.f, px = 0.f;
+#pragma unroll
+                  for (int j = 0; j < 4; j += 2) {
+                    const float v0 = gn * ev[j] + vb[t][j];
+                    const float v1 = gn * ev[j + 1] + vb[t][j + 1];
+                    const float pp = v0 * v1;
+                    pl += fast_log2(pp);
+                    px += (x2[t][j] * v1 + x2[t][j + 1] * v0) * fast_rcp(pp);
+                  }
+                  if (DOST) {
+                    if (SPLIT) {
+                      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), vrs, voff + 16u * q + 64u * t, 0, 0);
+                    } else {
+                      const unsigned p0 = pk2(ev[0], ev[1]), p1 = pk2(ev[2], ev[3]);
+                      if (t < Tm) {
+                        if ((t & 1) == 0) { pk_even0 = p0; pk_even1 = p1; }
+                        else __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk_even0, pk_even1, p0, p1}, vrs, voff + 16u * q + 64u * (t >> 1), 0, 0);
+                      } else {
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{p0, p1}, vrs, voff + 8u * q + 32u * t, 0, 0);
+                      }
+                    }
+                  }
+                  ef += pl * LN2_F + px;
+                  if ((t & 1) == 1) { e += (double)ef; ef = 0.f; }
+                });
+      e += (double)ef;
+      return sum_rows4_d(e);
+    };
+
+    double Ecur = 0.0;
+    // it = -1 evaluates the initial state (mcem.py:392-400); it >= 0 are the MH steps.  With the store on and a
+    // burn-in, one more pass after the burn-in re-evaluates the state the chain is in (nothing drawn, nothing
+    // decided) so that its variances are on record in slot R.
+    const bool reeval = STORE && a.burnin > 0;
+    for (int it = -1; it < S + (reeval ? 1 : 0); ++it) {
+      asm volatile("" ::: "memory");            // the LDS-resident weights are re-read every step (no hoisting into registers)
+      const bool re = reeval && it == a.burnin;
+      const int m = (reeval && it > a.burnin) ? it - 1 : it;
+      const bool step = m >= 0 && !re;
+      // ---- noise of this step and the proposal Z' = Z + sqrt(var) randn (mcem.py:407)
+      float zp[8];
+      float lu = 0.f;                                   // log U(0,1) of the frame (mcem.py:420), lanes q = 0
+      if (step) {
+        f32x4 e0, e1;
+        float uu = 0.5f;
+        if (a.rng_mode == VAENMF_RNG_DEVICE) {
+          e0 = normal4(st0);
+          if (q == 0) uu = uniform01(st0);
+          e1 = normal4(st1);
+        } else {
+          const size_t row = (size_t)m * a.NT + nrow;
+          e0 = *reinterpret_cast<const f32x4*>(a.eps + row * LAT + 4 * q);
+          e1 = *reinterpret_cast<const f32x4*>(a.eps + row * LAT + 16 + 4 * q);
+          uu = a.u[row];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { zp[t] = z[t] + a.sd * e0[t]; zp[4 + t] = z[4 + t] + a.sd * e1[t]; }
+        lu = q == 0 ? fast_log(uu) : 0.f;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) zp[t] = z[t];
+      }
+      const int slot = !STORE ? -1 : (re ? a.nsamples : (m >= a.burnin ? m - a.burnin : ((m < 0 && a.burnin == 0) ? a.nsamples : -1)));
+      double Ep;
+      if (STORE && slot >= 0) Ep = energy(zp, slot, std::true_type{});
+      else Ep = energy(zp, slot, std::false_type{});
+      if (re) continue;
+      float pr = 0.f;                                   // .5 * sum(Z^2 - Z'^2)   (mcem.py:417)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pr += z[j] * z[j] - zp[j] * zp[j];
+      pr = sum_rows4(pr);
+      lu = sum_rows4(lu);                               // every lane of the frame gets log u
+      const float accp = (float)(Ecur - Ep) + 0.5f * pr;
+      const bool ok = m < 0 || lu < accp;               // mcem.py:420
+      if (a.acc_out && m >= 0 && q == 0 && fvalid) a.acc_out[(size_t)m * a.NT + nrow] = accp;
+      if (ok) {                                         // mcem.py:429-433
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = zp[j];
+        Ecur = Ep;
+        if (STORE && m >= a.burnin) cur_src = m - a.burnin;
+      }
+      if (m >= a.burnin && fvalid) {                    // mcem.py:435-437
+        if (STORE && q == 0) a.src[(size_t)(m - a.burnin) * a.NT + nrow] = cur_src;
+        float* dst = a.Zs + ((size_t)nrow * a.Rcap + (m - a.burnin)) * LAT;
+        *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{z[0], z[1], z[2], z[3]};
+        *reinterpret_cast<f32x4*>(dst + 16 + 4 * q) = f32x4{z[4], z[5], z[6], z[7]};
+      }
+    }
+    if (a.update_Z && fvalid) {                         // self.Z = last draw (mcem.py:466)
+      float* dst = a.Z + (size_t)nrow * LAT;
+      *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{z[0], z[1], z[2], z[3]};
+      *reinterpret_cast<f32x4*>(dst + 16 + 4 * q) = f32x4{z[4], z[5], z[6], z[7]};
+    }
+  }
+}
+
+}  // namespace
+
+// ============================================================================
+// Host side
+// ============================================================================
+int vn_ensure_dyn_lds(const void* fn, int bytes);     // plan.hip: per-device hipFuncSetAttribute, checked
+
+namespace {
+
+constexpr int WC_LDS_LIMIT = 160 * 1024;
+
+template <int MAXT, bool EXACT, bool SPLIT, bool STORE, int NWAVES, bool LOL, bool HIALL, bool M2>
+int wc_launch(const WcArgs& a, int grid, size_t lds, hipStream_t st) {
+  auto* fn = wchain_kernel<MAXT, EXACT, SPLIT, STORE, NWAVES, LOL, HIALL, M2>;
+  if (int e = vn_ensure_dyn_lds((const void*)fn, WC_LDS_LIMIT)) return e;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(NWAVES * 64), lds, st, a);
+  return 0;
+}
+// M1 runs NW1 wavefronts per workgroup, M2 (32 more registers: the per-frame layer-1 bias) always 4
+template <int MAXT, bool EXACT, bool SPLIT, int NW1, bool LOL>
+int wc_launch_s(const WcArgs& a, int nwt, int n_sms, size_t lds, hipStream_t st) {
+  const int nw = a.B1 ? 4 : NW1;
+  int grid = (nwt + nw - 1) / nw;
+  if (grid > n_sms) grid = n_sms;                       // one workgroup per CU (LDS), wave tiles in a grid-stride loop
+  if (a.B1) {
+#if !defined(VN_DEV_FAST) || defined(VN_DEV_M2)
+    return a.VsS ? wc_launch<MAXT, EXACT, SPLIT, true, 4, LOL, true, true>(a, grid, lds, st)
+                 : wc_launch<MAXT, EXACT, SPLIT, false, 4, LOL, true, true>(a, grid, lds, st);
+#else
+    return -1;
+#endif
+  }
+  return a.VsS ? wc_launch<MAXT, EXACT, SPLIT, true, NW1, LOL, true, false>(a, grid, lds, st)
+               : wc_launch<MAXT, EXACT, SPLIT, false, NW1, LOL, true, false>(a, grid, lds, st);
+}
+
+}  // namespace
+
+// Shapes the wave-private chain covers (the rest runs engine.hip's team kernel): every W3 hi fragment in LDS
+bool vn_wchain_supported(const vaenmf_plan* p) {
+  if (p->NT3c > 17) return false;
+  const char* e = getenv("VAENMF_TEAM_CHAIN");          // dev / test override: force the team kernel of engine.hip
+  return !(e && e[0] == '1');
+}
+
+int vn_launch_wchain(vaenmf_plan* p, const VnChainCall& cc, hipStream_t st) {
+  const bool split = p->cfg.precision == VAENMF_PREC_BF16X3;
+  WcArgs a = {};
+  a.w1f = p->w1f; a.w2f = p->w2f; a.w3f = p->w3c; a.b1 = p->b1; a.b2 = p->b2; a.b3 = p->b3c;
+  a.NT3 = p->NT3c; a.Tm = split ? 0 : ((p->NT3c - 1) & ~1); a.F = p->cfg.F; a.Fs = p->Fs;
+  a.X2 = cc.X2; a.W = cc.W; a.Ht = cc.Ht; a.g = cc.g; a.B1 = cc.B1; a.Vb = p->Vb_ext;
+  a.Z = cc.Z; a.Zs = cc.Zs; a.acc_out = cc.acc_out;
+  a.VsS = cc.VsS; a.VsS_bytes = (unsigned)cc.VsS_bytes; a.src = cc.src; a.Rs = cc.Rs;
+  a.wt_utt = p->d_wt_utt; a.wt_n0 = p->d_wt_n0; a.wt_cnt = p->d_wt_cnt; a.n_wtiles = p->n_wtiles;
+  a.frame_off = p->d_frame_off; a.utt_seed = p->d_utt_seed; a.eps = cc.eps; a.u = cc.u;
+  a.Kp = p->Kp; a.NT = p->NT; a.Rcap = cc.Rcap; a.nsamples = cc.nsamples; a.burnin = cc.burnin;
+  a.rng_mode = cc.rng_mode; a.update_Z = cc.update_Z; a.call = cc.call; a.sd = cc.sd;
+  a.n_hi_lds = p->NT3c;
+  const size_t fixed = split ? WcLds<true>::fixed_bytes : WcLds<false>::fixed_bytes;
+  const size_t w3hi = (size_t)p->NT3c * NK * 1024;
+  const bool lol = split && p->NT3c <= 5;              // bf16x3: the lo fragments of W3 fit in LDS up to 5 tiles (F <= 80), else they stream from L2
+  const size_t lds = fixed + w3hi * (lol ? 2 : 1);
+  VN_REQUIRE(lds <= (size_t)WC_LDS_LIMIT, "wave chain: %zu bytes of LDS needed", lds);
+  // wavefronts per workgroup: 8 (two per SIMD, 256 registers each) in bf16 mode, 4 (512 registers) in bf16x3 mode
+  constexpr int NW_BF16 = VN_WC_WAVES_BF16, NW_X3 = 4;
+  int rc = -1;
+  if (p->NT3c == 17)     rc = split ? wc_launch_s<17, true, true, NW_X3, false>(a, p->n_wtiles, p->n_sms, lds, st) : wc_launch_s<17, true, false, NW_BF16, false>(a, p->n_wtiles, p->n_sms, lds, st);
+  else if (p->NT3c == 5) rc = split ? wc_launch_s<5, true, true, NW_X3, true>(a, p->n_wtiles, p->n_sms, lds, st)   : wc_launch_s<5, true, false, NW_BF16, false>(a, p->n_wtiles, p->n_sms, lds, st);
+#ifndef VN_DEV_FAST
+  else if (p->NT3c < 5)  rc = split ? wc_launch_s<5, false, true, NW_X3, true>(a, p->n_wtiles, p->n_sms, lds, st)  : wc_launch_s<5, false, false, NW_BF16, false>(a, p->n_wtiles, p->n_sms, lds, st);
+  else                   rc = split ? wc_launch_s<17, false, true, NW_X3, false>(a, p->n_wtiles, p->n_sms, lds, st) : wc_launch_s<17, false, false, NW_BF16, false>(a, p->n_wtiles, p->n_sms, lds, st);
+#endif
+  VN_REQUIRE(rc != -1, "wave chain: shape not compiled in (dev build)");
+  if (rc) return rc;
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}

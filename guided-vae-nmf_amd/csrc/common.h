@@ -54,6 +54,14 @@ struct vaenmf_plan {
   int32_t *d_tile_utt, *d_tile_n0, *d_tile_cnt;   // MH-chain tiles (<=32 frames, one utterance each)
   int32_t *d_frame_utt;      // [NT]
   int32_t *d_frame_loc;      // [NT] frame index inside its utterance
+  // wave-private chain (chain.hip): all F bins on the MFMA path, W3 / b3 in the chain's bin order; wave tiles
+  __bf16* w3c;               // [NT3c][kstep][part][lane][8]
+  float* b3c;                // [16 NT3c], padding -200
+  int NT3c;                  // ceil(F / 16)
+  int32_t *d_wt_utt, *d_wt_n0, *d_wt_cnt;         // wave tiles (<= 16 frames of one utterance each)
+  int n_wtiles;
+  int Rcap_store;            // samples per frame the store was sized for at vaenmf_bind_batch / vaenmf_sample_store
+  int last_m_step_path;      // VAENMF_Q_MSTEP_PATH: 0 none yet, 1 stored (streaming), 2 decoding
   uint64_t* d_utt_seed;      // [n_utt]
   std::vector<int32_t> h_frame_off;
   // workspace
@@ -73,6 +81,17 @@ struct vaenmf_plan {
   std::vector<hipEvent_t> prof_ev;      // pairs (start, stop)
   std::vector<int> prof_kind;
   size_t prof_used;
+};
+
+// one MH-chain call, as vaenmf_mh_chain hands it to the kernel launchers (engine.hip team kernel, chain.hip wave kernel)
+struct VnChainCall {
+  const float *X2, *W, *Ht, *g, *B1;
+  float *Z, *Zs, *acc_out;
+  const float *eps, *u;
+  void* VsS; size_t VsS_bytes; int32_t* src; int Rs;
+  int Rcap, nsamples, burnin, rng_mode, update_Z;
+  uint32_t call;
+  float sd;
 };
 
 enum { VN_K_CHAIN = 0, VN_K_WSTATS = 1, VN_K_WUPDATE = 2, VN_K_HG = 3, VN_K_WF = 4, VN_K_NKINDS = 5 };

@@ -1281,6 +1281,8 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void decode_kernel(const DecodeArg
 // ============================================================================
 // Host launchers (C ABI)
 // ============================================================================
+int vn_ensure_dyn_lds(const void* fn, int bytes);     // plan.hip
+
 namespace {
 
 DecW make_decw(const vaenmf_plan* p) {
@@ -1307,15 +1309,14 @@ template <int NW, int NTEAM, int MT, bool SPLIT, bool STORE>
 int launch_chain_s(ChainArgs a, int n_tiles, hipStream_t st) {
   size_t lds;
   lds_plan<NTEAM, SPLIT>(a.dw.NT3, sizeof(ChainX), &a.w3_lds_off, &lds);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, NTEAM, MT, SPLIT, true, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-    (void)hipFuncSetAttribute((const void*)mh_chain_kernel<NW, NTEAM, MT, SPLIT, false, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-    attr_done = true;
-  }
   const dim3 blk(NW * NTEAM * 64);
-  if (a.w3_lds_off >= 0) hipLaunchKernelGGL((mh_chain_kernel<NW, NTEAM, MT, SPLIT, true, STORE>), dim3(n_tiles), blk, lds, st, a);
-  else                   hipLaunchKernelGGL((mh_chain_kernel<NW, NTEAM, MT, SPLIT, false, STORE>), dim3(n_tiles), blk, lds, st, a);
+  if (a.w3_lds_off >= 0) {
+    if (int e = vn_ensure_dyn_lds((const void*)mh_chain_kernel<NW, NTEAM, MT, SPLIT, true, STORE>, LDS_LIMIT)) return e;
+    hipLaunchKernelGGL((mh_chain_kernel<NW, NTEAM, MT, SPLIT, true, STORE>), dim3(n_tiles), blk, lds, st, a);
+  } else {
+    if (int e = vn_ensure_dyn_lds((const void*)mh_chain_kernel<NW, NTEAM, MT, SPLIT, false, STORE>, LDS_LIMIT)) return e;
+    hipLaunchKernelGGL((mh_chain_kernel<NW, NTEAM, MT, SPLIT, false, STORE>), dim3(n_tiles), blk, lds, st, a);
+  }
   return 0;
 }
 template <int NW, int NTEAM, int MT, bool SPLIT>
@@ -1324,16 +1325,16 @@ int launch_chain(const ChainArgs& a, int n_tiles, hipStream_t st) {
 }
 
 template <int NW, int NTEAM, int MT, bool SPLIT, int MODE, int KP>
-void launch_decode_one(const DecodeArgs& a, int grid, size_t lds, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)decode_kernel<NW, NTEAM, MT, SPLIT, true, MODE, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-    (void)hipFuncSetAttribute((const void*)decode_kernel<NW, NTEAM, MT, SPLIT, false, MODE, KP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-    attr_done = true;
-  }
+int launch_decode_one(const DecodeArgs& a, int grid, size_t lds, hipStream_t st) {
   const dim3 blk(NW * NTEAM * 64);
-  if (a.w3_lds_off >= 0) hipLaunchKernelGGL((decode_kernel<NW, NTEAM, MT, SPLIT, true, MODE, KP>), dim3(grid), blk, lds, st, a);
-  else                   hipLaunchKernelGGL((decode_kernel<NW, NTEAM, MT, SPLIT, false, MODE, KP>), dim3(grid), blk, lds, st, a);
+  if (a.w3_lds_off >= 0) {
+    if (int e = vn_ensure_dyn_lds((const void*)decode_kernel<NW, NTEAM, MT, SPLIT, true, MODE, KP>, LDS_LIMIT)) return e;
+    hipLaunchKernelGGL((decode_kernel<NW, NTEAM, MT, SPLIT, true, MODE, KP>), dim3(grid), blk, lds, st, a);
+  } else {
+    if (int e = vn_ensure_dyn_lds((const void*)decode_kernel<NW, NTEAM, MT, SPLIT, false, MODE, KP>, LDS_LIMIT)) return e;
+    hipLaunchKernelGGL((decode_kernel<NW, NTEAM, MT, SPLIT, false, MODE, KP>), dim3(grid), blk, lds, st, a);
+  }
+  return 0;
 }
 template <int NW, int NTEAM, int MT, bool SPLIT, int MODE>
 int launch_decode_kp(DecodeArgs a, int Kp, int grid, hipStream_t st) {
@@ -1344,11 +1345,10 @@ int launch_decode_kp(DecodeArgs a, int Kp, int grid, hipStream_t st) {
   lds_plan<NTEAM, SPLIT>(a.dw.NT3, (x_bytes + wl_bytes + NTEAM - 1) / NTEAM, &a.w3_lds_off, &lds);
   a.wl_lds_off = (int)(LdsMap<NTEAM, SPLIT>::common_end + x_bytes);
   switch (Kp) {
-    case 8:  launch_decode_one<NW, NTEAM, MT, SPLIT, MODE, 8>(a, grid, lds, st); break;
-    case 16: launch_decode_one<NW, NTEAM, MT, SPLIT, MODE, 16>(a, grid, lds, st); break;
-    default: launch_decode_one<NW, NTEAM, MT, SPLIT, MODE, 32>(a, grid, lds, st); break;
+    case 8:  return launch_decode_one<NW, NTEAM, MT, SPLIT, MODE, 8>(a, grid, lds, st);
+    case 16: return launch_decode_one<NW, NTEAM, MT, SPLIT, MODE, 16>(a, grid, lds, st);
+    default: return launch_decode_one<NW, NTEAM, MT, SPLIT, MODE, 32>(a, grid, lds, st);
   }
-  return 0;
 }
 // workgroup geometry (plan.hip picks it from the number of bin tiles NT3 of the MFMA path):
 //   0 = 2 teams x 4 waves, 5 bin tiles per wave (NT3 <= 20)      3 = 2 teams x 4 waves, 4 tiles (NT3 <= 16)
@@ -1384,6 +1384,9 @@ int check_bound(const vaenmf_plan* p) {
 
 }  // namespace
 
+// chain.hip
+bool vn_wchain_supported(const vaenmf_plan* p);
+int vn_launch_wchain(vaenmf_plan* p, const VnChainCall& cc, hipStream_t st);
 // aux.hip
 int vn_launch_w_update(const vaenmf_plan* p, float* W, const float* Ht, hipStream_t st);
 int vn_launch_cost_reduce(const vaenmf_plan* p, const double* cost_frames, int R, double* cost, int niter, int it, hipStream_t st);
@@ -1405,42 +1408,69 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
   hipStream_t st = (hipStream_t)stream;
   const bool split = p->cfg.precision == VAENMF_PREC_BF16X3;
   p->store_R = p->store_Rs = 0;
-  if (p->store_on) {                                    // sample-variance store: grown on demand, reused across calls
+  size_t vss_bytes = 0;
+  if (p->store_on) {                                    // sample-variance store: sized by vaenmf_sample_store, never here
     const int Rs = nsamples + 1;
     const size_t esz = split ? sizeof(float) : sizeof(__bf16);
     const size_t need_v = (size_t)(p->NT + 1) * Rs * p->Fs * esz, need_s = (size_t)p->NT * Rs;   // + a spare block (idle lanes)
     VN_REQUIRE(need_v < (1ull << 32), "sample store: %d frames x %d slots x %d bins exceeds the 32-bit byte offsets of "
                "the chain kernel; bind a smaller batch or switch the store off", p->NT, Rs, p->Fs);
-    if (need_v > p->VsS_cap) {
-      if (p->VsS) VN_CHECK_HIP(hipFree(p->VsS));
-      p->VsS = nullptr; p->VsS_cap = 0;
-      VN_CHECK_HIP(hipMalloc(&p->VsS, need_v));
-      p->VsS_cap = need_v;
-    }
-    if (need_s > p->src_cap) {
-      if (p->src) VN_CHECK_HIP(hipFree(p->src));
-      p->src = nullptr; p->src_cap = 0;
-      VN_CHECK_HIP(hipMalloc(&p->src, need_s * sizeof(int32_t)));
-      p->src_cap = need_s;
-    }
+    VN_REQUIRE(need_v <= p->VsS_cap && need_s <= p->src_cap, "sample store too small for %d frames x %d samples: call "
+               "vaenmf_sample_store(plan, max_samples) after vaenmf_bind_batch (no allocation happens in vaenmf_mh_chain)", p->NT, nsamples);
     a.VsS = p->VsS; a.src = p->src; a.Rs = Rs;
+    vss_bytes = need_v;
+  }
+  if (vn_wchain_supported(p)) {                         // wave-private chains (chain.hip)
+    VnChainCall cc = {};
+    cc.X2 = X2; cc.W = W; cc.Ht = Ht; cc.g = g; cc.B1 = B1; cc.Z = Z; cc.Zs = Zs; cc.acc_out = acc_out;
+    cc.eps = rng->eps; cc.u = rng->u; cc.VsS = a.VsS; cc.VsS_bytes = vss_bytes; cc.src = a.src; cc.Rs = a.Rs;
+    cc.Rcap = Rcap; cc.nsamples = nsamples; cc.burnin = burnin; cc.rng_mode = rng->mode; cc.update_Z = update_Z;
+    cc.call = rng->call; cc.sd = a.sd;
+    ProfScope ps(p, VN_K_CHAIN, st);
+    if (int e = vn_launch_wchain(p, cc, st)) return e;
+    if (p->store_on) { p->store_R = nsamples; p->store_Rs = nsamples + 1; }
+    return 0;
   }
   ProfScope ps(p, VN_K_CHAIN, st);
+  int lrc = 0;
   switch (p->geom) {
-    case 0: if (split) launch_chain<4, 2, 5, true>(a, p->n_tiles, st); else launch_chain<4, 2, 5, false>(a, p->n_tiles, st); break;
-    case 3: if (split) launch_chain<4, 2, 4, true>(a, p->n_tiles, st); else launch_chain<4, 2, 4, false>(a, p->n_tiles, st); break;
-    case 4: if (split) launch_chain<8, 1, 4, true>(a, p->n_tiles, st); else launch_chain<8, 1, 4, false>(a, p->n_tiles, st); break;
-    default: if (split) launch_chain<8, 1, 5, true>(a, p->n_tiles, st); else launch_chain<8, 1, 5, false>(a, p->n_tiles, st); break;
+    case 0: lrc = split ? launch_chain<4, 2, 5, true>(a, p->n_tiles, st) : launch_chain<4, 2, 5, false>(a, p->n_tiles, st); break;
+    case 3: lrc = split ? launch_chain<4, 2, 4, true>(a, p->n_tiles, st) : launch_chain<4, 2, 4, false>(a, p->n_tiles, st); break;
+    case 4: lrc = split ? launch_chain<8, 1, 4, true>(a, p->n_tiles, st) : launch_chain<8, 1, 4, false>(a, p->n_tiles, st); break;
+    default: lrc = split ? launch_chain<8, 1, 5, true>(a, p->n_tiles, st) : launch_chain<8, 1, 5, false>(a, p->n_tiles, st); break;
   }
+  if (lrc) return lrc;
   VN_CHECK_HIP(hipGetLastError());
   if (p->store_on) { p->store_R = nsamples; p->store_Rs = nsamples + 1; }
   return 0;
 }
 
-extern "C" int vaenmf_sample_store(vaenmf_plan* p, int32_t enable) {
+// max_samples > 0: switch the store on and size it for chains of up to max_samples samples per frame over the
+// plan's frame capacity (an allocating call, like vaenmf_plan_create); 0: off (the memory is kept).
+extern "C" int vaenmf_sample_store(vaenmf_plan* p, int32_t max_samples) {
   VN_REQUIRE(p != nullptr, "null plan");
-  p->store_on = enable != 0;
+  VN_REQUIRE(max_samples >= 0, "max_samples = %d", max_samples);
   p->store_R = p->store_Rs = 0;
+  p->store_on = max_samples > 0;
+  if (!p->store_on) return 0;
+  const size_t esz = p->cfg.precision == VAENMF_PREC_BF16X3 ? sizeof(float) : sizeof(__bf16);
+  // sized for the bound batch (or, before a batch is bound, for the plan's frame capacity)
+  const size_t frames = (size_t)(p->NT > 0 ? p->NT : p->cfg.max_frames) + 1, Rs = (size_t)max_samples + 1;
+  size_t need_v = frames * Rs * p->Fs * esz, need_s = frames * Rs;
+  if (need_v >= (1ull << 32)) need_v = (1ull << 32) - 16;      // larger batches fall back to decoding (vaenmf_em_run)
+  if (need_v > p->VsS_cap) {
+    if (p->VsS) VN_CHECK_HIP(hipFree(p->VsS));
+    p->VsS = nullptr; p->VsS_cap = 0;
+    VN_CHECK_HIP(hipMalloc(&p->VsS, need_v));
+    p->VsS_cap = need_v;
+  }
+  if (need_s > p->src_cap) {
+    if (p->src) VN_CHECK_HIP(hipFree(p->src));
+    p->src = nullptr; p->src_cap = 0;
+    VN_CHECK_HIP(hipMalloc(&p->src, need_s * sizeof(int32_t)));
+    p->src_cap = need_s;
+  }
+  p->Rcap_store = max_samples;
   return 0;
 }
 
@@ -1532,6 +1562,7 @@ extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* H
   auto fits = [&](int ns) { return (size_t)(p->NT + 1) * (ns + 1) * p->Fs * 4 < (1ull << 32) && p->Fm <= 768; };
   const bool want = p->store_on, stored = want && fits(nsE) && fits(nsWF);
   p->store_on = stored;
+  p->last_m_step_path = stored ? 1 : 2;               // VAENMF_Q_MSTEP_PATH: the caller can see a fall back to decoding
   struct Restore { vaenmf_plan* p; bool v; ~Restore() { p->store_on = v; } } restore{p, want};
   for (int it = 0; it < niter; ++it) {                  // EM.run, mcem.py:159-165
     rng.call = (uint32_t)it;

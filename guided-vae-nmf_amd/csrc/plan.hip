@@ -5,9 +5,25 @@
 #include <string.h>
 #include <math.h>
 #include <stdlib.h>
+#include <mutex>
+#include <set>
+#include <utility>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember (device, kernel) pairs, check the result
+int vn_ensure_dyn_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  VN_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({dev, fn})) return 0;
+  VN_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({dev, fn});
+  return 0;
+}
 
 void vaenmf_set_error(const char* fmt, ...) {
   va_list ap;
@@ -91,8 +107,11 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
     p->nwaves = (geom == 0 || geom == 3) ? 4 : 8;
     p->tile_frames = (geom == 0 || geom == 3) ? 64 : 32;
   }
-  p->w1f = p->w2f = p->w3f = nullptr;
-  p->b1 = p->b2 = p->b3 = p->w1y = p->w3n = nullptr;
+  p->NT3c = (cfg->F + 15) / 16;
+  p->w1f = p->w2f = p->w3f = p->w3c = nullptr;
+  p->b1 = p->b2 = p->b3 = p->w1y = p->w3n = p->b3c = nullptr;
+  p->d_wt_utt = p->d_wt_n0 = p->d_wt_cnt = nullptr;
+  p->n_wtiles = 0; p->Rcap_store = 0; p->last_m_step_path = 0;
   p->Dy = 0;
   p->have_weights = false;
   p->Vb_ext = nullptr;
@@ -115,6 +134,12 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   e |= dev_alloc(&p->b2, HID);
   e |= dev_alloc(&p->b3, p->Fs);
   e |= dev_alloc(&p->w3n, HID);
+  e |= dev_alloc(&p->w3c, (size_t)p->NT3c * (HID / 32) * 2 * 64 * 8);
+  e |= dev_alloc(&p->b3c, (size_t)p->NT3c * 16);
+  const size_t max_wtiles = NTc / 16 + Uc + 1;
+  e |= dev_alloc(&p->d_wt_utt, max_wtiles);
+  e |= dev_alloc(&p->d_wt_n0, max_wtiles);
+  e |= dev_alloc(&p->d_wt_cnt, max_wtiles);
   e |= dev_alloc(&p->d_frame_off, Uc + 1);
   e |= dev_alloc(&p->d_tile_utt, max_tiles);
   e |= dev_alloc(&p->d_tile_n0, max_tiles);
@@ -136,7 +161,7 @@ extern "C" void vaenmf_plan_destroy(vaenmf_plan* p) {
   if (!p) return;
   void* ptrs[] = {p->w1f, p->w2f, p->w3f, p->b1, p->b2, p->b3, p->w3n, p->w1y, p->d_frame_off, p->d_tile_utt, p->d_tile_n0,
                   p->d_tile_cnt, p->d_frame_utt, p->d_frame_loc, p->d_utt_seed, p->A1, p->P, p->normW, p->wpart, p->cost_frames,
-                  p->VsS, p->src};
+                  p->VsS, p->src, p->w3c, p->b3c, p->d_wt_utt, p->d_wt_n0, p->d_wt_cnt};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
@@ -151,6 +176,8 @@ extern "C" int vaenmf_plan_query(const vaenmf_plan* p, int32_t what) {
     case VAENMF_Q_TILES: return p->n_tiles;
     case VAENMF_Q_NT: return p->NT;
     case VAENMF_Q_NUTT: return p->n_utt;
+    case VAENMF_Q_MSTEP_PATH: return p->last_m_step_path;
+    case VAENMF_Q_WTILES: return p->n_wtiles;
     default: return -1;
   }
 }
@@ -183,6 +210,24 @@ extern "C" int vaenmf_set_decoder_weights(vaenmf_plan* p, const float* W1, int32
   e |= upload(p->b2, b2s.data(), HID);
   e |= upload(p->b3, b3p.data(), b3p.size());
   e |= upload(p->w3n, W3s.data() + (size_t)(F - 1) * HID, HID);
+  {
+    // chain.hip: every bin on the MFMA path; bf16 mode pairs the tiles (bin = 32 (t>>1) + 8 q + 4 (t&1) + j for
+    // row 4 q + j of tile t < Tm), bf16x3 mode keeps the natural order; padding rows: W3 = 0, b3 = -200 (Vs = 0)
+    const int NT3c = p->NT3c, Tm = p->cfg.precision == VAENMF_PREC_BF16X3 ? 0 : ((NT3c - 1) & ~1);
+    std::vector<float> Wp((size_t)16 * NT3c * HID, 0.f), bp((size_t)16 * NT3c, -200.f);
+    for (int t = 0; t < NT3c; ++t)
+      for (int i = 0; i < 16; ++i) {
+        const int q = i >> 2, j = i & 3;
+        const int bin = t < Tm ? 32 * (t >> 1) + 8 * q + 4 * (t & 1) + j : 16 * t + i;
+        if (bin < F) {
+          memcpy(&Wp[(size_t)(16 * t + i) * HID], W3s.data() + (size_t)bin * HID, sizeof(float) * HID);
+          bp[16 * t + i] = b3s[bin];
+        }
+      }
+    std::vector<uint16_t> f3c = pack_weights(Wp.data(), 16 * NT3c, HID, HID, NT3c, HID / 32);
+    e |= upload((uint16_t*)p->w3c, f3c.data(), f3c.size());
+    e |= upload(p->b3c, bp.data(), bp.size());
+  }
   if (p->w1y) { (void)hipFree(p->w1y); p->w1y = nullptr; }
   p->Dy = in1 - LAT;
   if (p->Dy > 0) {                             // label columns of W1 (scaled like the rest of layer 1), [H1][Dy]
@@ -213,6 +258,13 @@ extern "C" int vaenmf_bind_batch(vaenmf_plan* p, int32_t n_utt, const int32_t* f
     }
     for (int n = b; n < e; ++n) { f_utt[n] = u; f_loc[n] = n - b; }
   }
+  std::vector<int32_t> w_utt, w_n0, w_cnt;              // wave tiles of the wave-private chain (chain.hip)
+  for (int u = 0; u < n_utt; ++u)
+    for (int n = frame_offsets[u]; n < frame_offsets[u + 1]; n += 16) {
+      w_utt.push_back(u);
+      w_n0.push_back(n);
+      w_cnt.push_back(frame_offsets[u + 1] - n < 16 ? frame_offsets[u + 1] - n : 16);
+    }
   std::vector<uint64_t> seeds(n_utt);
   for (int u = 0; u < n_utt; ++u) {
     uint64_t x = 0x5EEDull + (uint64_t)u;
@@ -226,7 +278,12 @@ extern "C" int vaenmf_bind_batch(vaenmf_plan* p, int32_t n_utt, const int32_t* f
   e |= upload(p->d_frame_utt, f_utt.data(), f_utt.size());
   e |= upload(p->d_frame_loc, f_loc.data(), f_loc.size());
   e |= upload(p->d_utt_seed, seeds.data(), seeds.size());
+  e |= upload(p->d_wt_utt, w_utt.data(), w_utt.size());
+  e |= upload(p->d_wt_n0, w_n0.data(), w_n0.size());
+  e |= upload(p->d_wt_cnt, w_cnt.data(), w_cnt.size());
   if (e) return -2;
+  p->n_wtiles = (int)w_utt.size();
+  p->store_R = p->store_Rs = 0;                         // the store's contents belong to the previous batch
   p->n_utt = n_utt;
   p->NT = NT;
   p->n_tiles = (int)t_utt.size();

@@ -22,6 +22,8 @@
 #define VN_WS_WAVES 4
 #endif
 
+int vn_ensure_dyn_lds(const void* fn, int bytes);     // plan.hip
+
 namespace {
 
 struct StreamArgs {
@@ -609,33 +611,30 @@ StreamArgs base_args(const vaenmf_plan* p) {
 enum { SK_WSTATS, SK_HG, SK_WF };
 
 template <int KIND, int NCH, int KP, typename ST>
-void launch_st(StreamArgs a, int grid, hipStream_t st) {
+int launch_st(StreamArgs a, int grid, hipStream_t st) {
   // rank <= 8: one W[utt] per wavefront; above: one per workgroup when it leaves room for two workgroups per CU
   const size_t one = (size_t)a.Fs * KP * sizeof(float);
   const size_t lds = KP <= 8 ? 4 * one : (one <= 72 * 1024 ? one : 0);
   a.w_blk_lds = KP > 8 && lds > 0;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)wstats_stream_kernel<NCH, KP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)hg_stream_kernel<NCH, KP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)wf_stream_kernel<NCH, KP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    attr_done = true;
-  }
+  const void* fn = KIND == SK_WSTATS ? (const void*)wstats_stream_kernel<NCH, KP, ST>
+                   : (KIND == SK_HG ? (const void*)hg_stream_kernel<NCH, KP, ST> : (const void*)wf_stream_kernel<NCH, KP, ST>);
+  if (int e = vn_ensure_dyn_lds(fn, 80 * 1024)) return e;
   if (KIND == SK_WSTATS) hipLaunchKernelGGL((wstats_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
   else if (KIND == SK_HG) hipLaunchKernelGGL((hg_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
   else hipLaunchKernelGGL((wf_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
+  return 0;
 }
 template <int KIND, int NCH, int KP>
-void launch_one(const StreamArgs& a, int grid, hipStream_t st) {
-  if (a.store_f32) launch_st<KIND, NCH, KP, float>(a, grid, st);
-  else launch_st<KIND, NCH, KP, __bf16>(a, grid, st);
+int launch_one(const StreamArgs& a, int grid, hipStream_t st) {
+  if (a.store_f32) return launch_st<KIND, NCH, KP, float>(a, grid, st);
+  return launch_st<KIND, NCH, KP, __bf16>(a, grid, st);
 }
 template <int KIND, int NCH>
-void launch_kp(const StreamArgs& a, int Kp, int grid, hipStream_t st) {
+int launch_kp(const StreamArgs& a, int Kp, int grid, hipStream_t st) {
   switch (Kp) {
-    case 8: launch_one<KIND, NCH, 8>(a, grid, st); break;
-    case 16: launch_one<KIND, NCH, 16>(a, grid, st); break;
-    default: launch_one<KIND, NCH, 32>(a, grid, st); break;
+    case 8: return launch_one<KIND, NCH, 8>(a, grid, st);
+    case 16: return launch_one<KIND, NCH, 16>(a, grid, st);
+    default: return launch_one<KIND, NCH, 32>(a, grid, st);
   }
 }
 template <int KIND>
@@ -647,9 +646,11 @@ int launch_stream(const vaenmf_plan* p, const StreamArgs& a, hipStream_t st) {
   // H/g is indifferent (4: 0.287, 8: 0.291, 16: 0.305)
   int grid = p->n_sms * 4;
   if (grid * 4 > p->NT) grid = (p->NT + 3) / 4;
-  if (nch <= 1) launch_kp<KIND, 1>(a, p->Kp, grid, st);
-  else if (nch == 2) launch_kp<KIND, 2>(a, p->Kp, grid, st);
-  else launch_kp<KIND, 3>(a, p->Kp, grid, st);
+  int rc;
+  if (nch <= 1) rc = launch_kp<KIND, 1>(a, p->Kp, grid, st);
+  else if (nch == 2) rc = launch_kp<KIND, 2>(a, p->Kp, grid, st);
+  else rc = launch_kp<KIND, 3>(a, p->Kp, grid, st);
+  if (rc) return rc;
   VN_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -185,8 +185,9 @@ class BatchEngine:
         return acc
 
     def sample_store(self, on=True):
-        """Keep the decoded variances of the chain's samples in HBM (see include/vaenmf.h)."""
-        check(lib().vaenmf_sample_store(self._plan, 1 if on else 0))
+        """Keep the decoded variances of the chain's samples in HBM (see include/vaenmf.h); sized here, for the
+        bound batch and chains of up to Rcap samples per frame (vaenmf_mh_chain itself never allocates)."""
+        check(lib().vaenmf_sample_store(self._plan, int(self.Rcap) if on else 0))
 
     def stored_variances(self, R):
         """Vs of the last chain's samples from the store: device float32 [NT,R,Fs]."""

@@ -51,7 +51,9 @@ enum { VAENMF_PREC_BF16X3 = 0,   /* bf16 MFMA, 3-term hi/lo split, fp32 accumula
 enum { VAENMF_RNG_REPLAY = 0,    /* caller supplies the normal / uniform draws (parity runs)          */
        VAENMF_RNG_DEVICE = 1 };  /* counter-seeded xoshiro128+ / Box-Muller streams on the device     */
 
-enum { VAENMF_Q_FS = 0, VAENMF_Q_KP = 1, VAENMF_Q_TILES = 2, VAENMF_Q_NT = 3, VAENMF_Q_NUTT = 4 };
+enum { VAENMF_Q_FS = 0, VAENMF_Q_KP = 1, VAENMF_Q_TILES = 2, VAENMF_Q_NT = 3, VAENMF_Q_NUTT = 4,
+       VAENMF_Q_MSTEP_PATH = 5,  /* M-step path of the last vaenmf_em_run: 1 = streaming the sample store, 2 = decoding */
+       VAENMF_Q_WTILES = 6 };    /* 16-frame wave tiles of the bound batch */
 
 enum { VAENMF_ACT_NONE = 0, VAENMF_ACT_TANH = 1, VAENMF_ACT_RELU = 2, VAENMF_ACT_SIGMOID = 3,
        VAENMF_ACT_STEP = 4 };   /* 1 if x > 0 else 0: sigmoid(x) > 0.5, scripts/evaluate_M2_vad.py:131 */
@@ -170,8 +172,12 @@ int vaenmf_dense(const float* X, int32_t M, int32_t in, int32_t ldx, const float
  * (vaenmf_m_step_stored, vaenmf_wiener_stored; vaenmf_em_run does so by itself).  The store
  * describes the most recent vaenmf_mh_chain call only.  vaenmf_sample_store_gather copies
  * the samples' rows out densely, Vs_out DEV float [NT][nsamples][Fs] (what vaenmf_decode
- * computes from Zs; bins >= F unspecified). */
-int vaenmf_sample_store(vaenmf_plan* plan, int32_t enable);
+ * computes from Zs; bins >= F unspecified).
+ * vaenmf_sample_store(plan, max_samples): max_samples > 0 switches the store on and sizes it -- an ALLOCATING call,
+ * like vaenmf_plan_create -- for the bound batch (call it after vaenmf_bind_batch; before any batch is bound: for
+ * the plan's frame capacity) and chains of up to max_samples samples per frame; 0 switches it off (memory kept).
+ * vaenmf_mh_chain never allocates: it fails with a message if the store is too small for its batch. */
+int vaenmf_sample_store(vaenmf_plan* plan, int32_t max_samples);
 int vaenmf_sample_store_gather(vaenmf_plan* plan, float* Vs_out, void* stream);
 /* vaenmf_m_step / vaenmf_wiener over the store of the most recent chain (same updates, same
  * outputs; the samples are the store's, so no Zs / B1 arguments). */

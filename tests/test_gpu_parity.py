@@ -624,8 +624,11 @@ def test_sample_store_holds_the_samples_variances():
             ref = eng.decode(ns)[:, :, :F].cpu().numpy()
             assert np.all(np.isfinite(got))
             # same MFMA products, accumulated with the operands in swapped roles: equal to rounding; bf16 mode
-            # stores bf16 rows (8 significant bits: relative rounding up to 2^-8)
-            assert np.max(np.abs(got - ref) / ref) < (2e-5 if prec == "bf16x3" else 4e-3), (prec, ns, bi)
+            # stores bf16 rows (8 significant bits: relative rounding up to 2^-8); the odd last bin is an fp32 dot
+            # product in the decoding kernel and a bf16 MFMA product in the chain (the mode's own tolerance)
+            rel = np.abs(got - ref) / ref
+            assert np.max(rel[:, :, :F - 1]) < (2e-5 if prec == "bf16x3" else 4e-3), (prec, ns, bi)
+            assert np.max(rel[:, :, F - 1]) < (2e-5 if prec == "bf16x3" else 5e-2), (prec, ns, bi)
             eng.sample_store(False)
 
 
@@ -634,9 +637,10 @@ def test_stored_m_step_and_wiener_match_the_decoding_ones(F, K, prec):
     """vaenmf_m_step_stored / vaenmf_wiener_stored (streaming the chain's stored variances) against
     vaenmf_m_step / vaenmf_wiener (decoding Zs again) from the same state and the same chain: the same W, H, g,
     cost and Wiener outputs up to summation order (bf16x3 mode, float rows: 2e-5 relative on the updates, 1e-6 on
-    the cost; bf16 mode, bf16 rows with up to 2^-8 relative rounding per stored variance: 3e-3 / 1e-4)."""
+    the cost; bf16 mode: bf16 rows with up to 2^-8 relative rounding per stored variance, and the odd last bin comes
+    from the chain's bf16 MFMA products in the store but from the decoding kernel's fp32 dot product: 1e-2 / 5e-4)."""
     need_gpu()
-    tu, tc, tw = (2e-5, 1e-6, 2e-5) if prec == "bf16x3" else (3e-3, 1e-4, 3e-3)
+    tu, tc, tw = (2e-5, 1e-6, 2e-5) if prec == "bf16x3" else (1e-2, 5e-4, 1e-2)
     params = orc.xavier_normal_params([F, 32, [128, 128]], seed=3, bias_std=0.1)
     counts, seeds = [37, 64, 70], [5, 6, 7]
     g = np.random.default_rng(8)

@@ -1,9 +1,20 @@
 #!/bin/bash
 # dev aid: build a variant of the library for A/B timing: tools/build_variant.sh <tag> [extra hipcc flags]
 # -> guided-vae-nmf_amd/vaenmf/libvaenmf_<tag>.so   (run with VAENMF_LIB=<path>; see tools/ab.sh)
+# Only the sources named in VN_VARIANT_SRCS (default: chain stream) are recompiled with the extra flags; the rest
+# comes from the objects of the main build.
 set -e
 tag=$1; shift
 cd "$(dirname "$0")/../guided-vae-nmf_amd/csrc"
-for s in engine aux plan labels stream; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 "$@" -c $s.hip -o /tmp/${s}_$tag.o & done
+srcs=${VN_VARIANT_SRCS:-"chain stream"}
+objs=""
+for s in engine chain aux plan labels stream; do
+  if [[ " $srcs " == *" $s "* ]]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 "$@" -c $s.hip -o /tmp/${s}_$tag.o &
+    objs="$objs /tmp/${s}_$tag.o"
+  else
+    objs="$objs $s.o"
+  fi
+done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../vaenmf/libvaenmf_$tag.so /tmp/engine_$tag.o /tmp/aux_$tag.o /tmp/plan_$tag.o /tmp/labels_$tag.o /tmp/stream_$tag.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../vaenmf/libvaenmf_$tag.so $objs
