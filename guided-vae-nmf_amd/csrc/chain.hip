@@ -17,6 +17,23 @@
 // keeps the natural order (bin = 16 t + 4 q + j).  The permutation is applied to W3 / b3 on the host.
 #include "common.h"
 
+// Diagnostic builds only (-DVN_STAMP): per-phase tick sums (s_memtime) of workgroup 0 / wave 0 into a debug buffer that
+// nothing else reads.  The shipped library never executes a stamp.
+#ifdef VN_STAMP
+__device__ long long g_wc_stamp[32];
+// (sums are kept in registers and written once per wave tile: a read-modify-write of the debug buffer inside the loop
+// would wait, through vmcnt, for every variance store in flight and time those instead)
+#define WC_STAMP_DECL long long _t_prev = (long long)__builtin_amdgcn_s_memtime(); long long _st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int _st_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define WC_STAMP(slot) do { long long _t = (long long)__builtin_amdgcn_s_memtime(); _st_acc[slot] += _t - _t_prev; _st_cnt[slot] += 1; _t_prev = _t; } while (0)
+#define WC_STAMP_FLUSH do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int _i = 0; _i < 8; ++_i) { g_wc_stamp[_i] += _st_acc[_i]; g_wc_stamp[16 + _i] += _st_cnt[_i]; } } } while (0)
+#else
+#define WC_STAMP_DECL
+#define WC_STAMP(slot)
+#define WC_STAMP_FLUSH
+#endif
+#ifndef VN_VPER
+#define VN_VPER 6
+#endif
 #ifndef VN_SB
 #define VN_SB __builtin_amdgcn_sched_barrier(0)
 #endif
@@ -26,6 +43,7 @@ namespace {
 constexpr int NK = HID / 32;      // k-steps over a hidden layer
 constexpr int NTH = HID / 16;     // feature tiles of a hidden layer
 constexpr int WT_FRAMES = 16;     // frames per wavefront
+constexpr unsigned WC_OOB = 0xF0000000u;   // byte offset behind every buffer of the chain (the host keeps them below 3.5 GB)
 #ifndef VN_WC_WAVES_BF16
 #define VN_WC_WAVES_BF16 8
 #endif
@@ -158,6 +176,11 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
   auto tile_on3 = [&](int n, int t) { return n != MAXT || EXACT || t < NT3; };      // (hidden layers: every tile)
 
   __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(a.VsS, 0, STORE ? (int)a.VsS_bytes : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t zs_rs = __builtin_amdgcn_make_buffer_rsrc(a.Zs, 0, (int)((unsigned)a.NT * (unsigned)a.Rcap * LAT * 4u), 0x00020000);
+  __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(a.src, 0, STORE ? (int)((unsigned)a.NT * (unsigned)a.Rs * 4u) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t acc_rs = __builtin_amdgcn_make_buffer_rsrc(a.acc_out, 0, a.acc_out ? (int)((unsigned)a.NT * (unsigned)S * 4u) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t eps_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.eps), 0, a.eps ? (int)((unsigned)a.NT * (unsigned)S * LAT * 4u) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t u_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u ? (int)((unsigned)a.NT * (unsigned)S * 4u) : 0, 0x00020000);
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int wt = blockIdx.x * NWAVES + wave; wt < a.n_wtiles; wt += gridDim.x * NWAVES) {
@@ -210,8 +233,15 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
     }
     // ---- sample-variance store: slot r of the frame holds the variances of the proposal of post-burn-in step r,
     // slot R the state the chain is in when the burn-in ends; src[r][frame] names the slot of the state after
-    // step r (mcem.py:429-437).  Lanes without a frame write to the spare frame block behind the last one.
-    const unsigned fbase = STORE ? (unsigned)(fvalid ? nrow : a.NT) * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(store_t) : 0u;
+    // step r (mcem.py:429-437).
+    // Every per-frame address of the loop is a buffer resource (SGPRs) + one 32-bit byte offset per lane: no 64-bit
+    // address pairs live across the chain (spilled, they were reloaded from scratch before each store, and a scratch
+    // reload waits for every store in flight: vmcnt counts in order).  Lanes without a frame get an offset behind
+    // the buffer's size: the hardware drops their stores and returns 0 for their loads, no predicate needed.
+    const unsigned fbase = STORE ? (fvalid ? (unsigned)nrow * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(store_t) : WC_OOB) : 0u;
+    const unsigned zs_off = fvalid ? ((unsigned)nrow * (unsigned)a.Rcap * LAT + 4u * q) * 4u : WC_OOB;      // Zs[nrow][r][4q..]
+    const unsigned fr_off = (fvalid && q == 0) ? (unsigned)nrow * 4u : WC_OOB;                                  // [step][nrow] tables
+    const unsigned rp_off = ((unsigned)nrow * LAT + 4u * q) * 4u;                                               // eps[step][nrow][4q..]
     int cur_src = a.nsamples;
     // ---- noise streams: this lane draws latents 4q..4q+3 (stream q) and 16+4q.. (stream 4+q) of its frame;
     // the streams are keyed by (utterance seed, frame inside the utterance, latent quad, chain call)
@@ -225,6 +255,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
     // E(z) = sum_f [log Vx + X2 / Vx] of this lane's frame (all lanes of the frame get the sum).  fp64 across
     // the tiles: the reference sums per-bin DIFFERENCES of two states (mcem.py:415-416); summing each state
     // separately needs the extra bits.
+    WC_STAMP_DECL
     auto energy = [&](const float (&zz)[8], int slot, auto dost) -> double {
       constexpr bool DOST = STORE && decltype(dost)::value;
       // byte offset of this lane's part of the row: frame block + slot + lane part; the tile is the instruction's
@@ -250,17 +281,20 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
       auto run_layer = [&](auto nks_c, auto ntiles_c, auto frag, auto bias, auto bop, auto epi) {
         constexpr int NKS = decltype(nks_c)::value, N = decltype(ntiles_c)::value;
         bf16x8 wh[2][NKS], wl[2][NKS];
-        f32x4 acc[2];
+        f32x4 acc[2], bnext;
 #pragma unroll
         for (int s = 0; s < NKS; ++s) frag(0, s, wh[0][s], wl[0][s]);
+        bnext = bias(0);
 #pragma unroll
         for (int t = 0; t <= N; ++t) {
+          const f32x4 bcur = bnext;
           if (t + 1 < N && tile_on3(N, t + 1)) {
 #pragma unroll
             for (int s = 0; s < NKS; ++s) frag(t + 1, s, wh[(t + 1) & 1][s], wl[(t + 1) & 1][s]);
+            bnext = bias(t + 1);
           }
           if (t < N && tile_on3(N, t)) {
-            f32x4 ac = bias(t);
+            f32x4 ac = bcur;
 #pragma unroll
             for (int s = 0; s < NKS; ++s) {
               bf16x8 ah, al;
@@ -270,6 +304,17 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
             acc[t & 1] = ac;
           }
           if (t > 0 && tile_on3(N, t - 1)) epi(t - 1, acc[(t - 1) & 1]);
+          // order inside the region: every MFMA of the tile followed by a share of the previous tile's epilogue.  A wave
+          // whose next instruction is an MFMA waiting for the matrix pipe (or for the accumulator of the MFMA before it)
+          // holds the SIMD's vector issue port -- measured: a wave of back-to-back MFMAs starves its SIMD partner's VALU
+          // stream (tools/ubench/overlap.hip) -- so the MFMAs are spaced by VALU work of the same wave
+          if (NKS > 1 && t > 0 && t < N) {
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+              __builtin_amdgcn_sched_group_barrier(0x402, VN_VPER, 0);    // VALU / transcendental
+            }
+          }
           VN_SB;
         }
       };
@@ -292,6 +337,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
                   [&](int, bf16x8& hi, bf16x8& lo) { hi = __builtin_bit_cast(bf16x8, bh[0]); lo = SPLIT ? __builtin_bit_cast(bf16x8, bl[0]) : hi; },
                   [&](int t, const f32x4 acc) { put(ch, cl, t, tanh4(acc)); });
       }
+      WC_STAMP(1);
       // ---- layer 2
       run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, NTH>{},
                 [&](int t, int s, bf16x8& hi, bf16x8& lo) {
@@ -302,6 +348,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
                 [&](int t) { return *reinterpret_cast<const f32x4*>(b2l + 16 * t + 4 * q); },
                 [&](int s, bf16x8& hi, bf16x8& lo) { hi = __builtin_bit_cast(bf16x8, ch[s]); lo = SPLIT ? __builtin_bit_cast(bf16x8, cl[s]) : hi; },
                 [&](int t, const f32x4 acc) { put(bh, bl, t, tanh4(acc)); });
+      WC_STAMP(2);
       // ---- output layer: each finished tile straight into the energy epilogue
       double e = 0.0;
       float ef = 0.f;
@@ -347,7 +394,16 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
                   if ((t & 1) == 1) { e += (double)ef; ef = 0.f; }
                 });
       e += (double)ef;
+      WC_STAMP(3);
+#ifdef VN_EXP_F32SUM
+      return (double)sum_rows4((float)e);
+#elif defined(VN_EXP_PRIO)
+      __builtin_amdgcn_s_setprio(3);
+      const double r_ = sum_rows4_d(e);
+      return r_;
+#else
       return sum_rows4_d(e);
+#endif
     };
 
     double Ecur = 0.0;
@@ -355,6 +411,9 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
     // burn-in, one more pass after the burn-in re-evaluates the state the chain is in (nothing drawn, nothing
     // decided) so that its variances are on record in slot R.
     const bool reeval = STORE && a.burnin > 0;
+    // retire the prologue's loads here: a counted vmcnt wait for them placed inside the loop would, on every later
+    // step, wait for the previous step's stores instead (vmcnt counts loads and stores in order)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0), gfx9 encoding
     for (int it = -1; it < S + (reeval ? 1 : 0); ++it) {
       asm volatile("" ::: "memory");            // the LDS-resident weights are re-read every step (no hoisting into registers)
       const bool re = reeval && it == a.burnin;
@@ -364,51 +423,69 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
       float zp[8];
       float lu = 0.f;                                   // log U(0,1) of the frame (mcem.py:420), lanes q = 0
       if (step) {
-        f32x4 e0, e1;
-        float uu = 0.5f;
+        // (the proposal is finished inside each generator branch and pinned there: were the two branches to join
+        // with the noise still in flight, the compiler would place the replay loads' vmcnt wait on the common path,
+        // where it drains the variance stores of the device-generator run: vmcnt counts loads and stores in order)
         if (a.rng_mode == VAENMF_RNG_DEVICE) {
-          e0 = normal4(st0);
-          if (q == 0) uu = uniform01(st0);
-          e1 = normal4(st1);
-        } else {
-          const size_t row = (size_t)m * a.NT + nrow;
-          e0 = *reinterpret_cast<const f32x4*>(a.eps + row * LAT + 4 * q);
-          e1 = *reinterpret_cast<const f32x4*>(a.eps + row * LAT + 16 + 4 * q);
-          uu = a.u[row];
-        }
+          const f32x4 e0 = normal4(st0);
+          const float uu = q == 0 ? uniform01(st0) : 0.5f;
+          const f32x4 e1 = normal4(st1);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { zp[t] = z[t] + a.sd * e0[t]; zp[4 + t] = z[4 + t] + a.sd * e1[t]; }
-        lu = q == 0 ? fast_log(uu) : 0.f;
+          for (int t = 0; t < 4; ++t) { zp[t] = z[t] + a.sd * e0[t]; zp[4 + t] = z[4 + t] + a.sd * e1[t]; }
+          lu = q == 0 ? fast_log(uu) : 0.f;
+        } else {
+          const unsigned so = (unsigned)m * (unsigned)a.NT;      // step offset in rows
+          const f32x4 e0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(eps_rs, rp_off + so * (LAT * 4u), 0, 0));
+          const f32x4 e1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(eps_rs, rp_off + so * (LAT * 4u) + 64u, 0, 0));
+          const float uu = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(u_rs, (unsigned)nrow * 4u + so * 4u, 0, 0));
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { zp[t] = z[t] + a.sd * e0[t]; zp[4 + t] = z[4 + t] + a.sd * e1[t]; }
+          lu = q == 0 ? fast_log(uu) : 0.f;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(zp[t]));
+          asm volatile("" : "+v"(lu));
+        }
       } else {
 #pragma unroll
         for (int t = 0; t < 8; ++t) zp[t] = z[t];
       }
+#ifdef VN_EXP_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      WC_STAMP(0);
       const int slot = !STORE ? -1 : (re ? a.nsamples : (m >= a.burnin ? m - a.burnin : ((m < 0 && a.burnin == 0) ? a.nsamples : -1)));
       double Ep;
       if (STORE && slot >= 0) Ep = energy(zp, slot, std::true_type{});
       else Ep = energy(zp, slot, std::false_type{});
+      WC_STAMP(5);
       if (re) continue;
       float pr = 0.f;                                   // .5 * sum(Z^2 - Z'^2)   (mcem.py:417)
 #pragma unroll
       for (int j = 0; j < 8; ++j) pr += z[j] * z[j] - zp[j] * zp[j];
       pr = sum_rows4(pr);
       lu = sum_rows4(lu);                               // every lane of the frame gets log u
+      WC_STAMP(6);
       const float accp = (float)(Ecur - Ep) + 0.5f * pr;
       const bool ok = m < 0 || lu < accp;               // mcem.py:420
-      if (a.acc_out && m >= 0 && q == 0 && fvalid) a.acc_out[(size_t)m * a.NT + nrow] = accp;
-      if (ok) {                                         // mcem.py:429-433
+      if (a.acc_out && m >= 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, accp), acc_rs, fr_off + (unsigned)m * (unsigned)a.NT * 4u, 0, 0);
+      // mcem.py:429-433, as selects (no divergent branch in the loop)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] = zp[j];
-        Ecur = Ep;
-        if (STORE && m >= a.burnin) cur_src = m - a.burnin;
+      for (int j = 0; j < 8; ++j) z[j] = ok ? zp[j] : z[j];
+      Ecur = ok ? Ep : Ecur;
+      WC_STAMP(7);
+      if (m >= a.burnin) {                              // (uniform) mcem.py:435-437
+        const unsigned r = (unsigned)(m - a.burnin);
+        if (STORE) {
+          cur_src = ok ? (int)r : cur_src;
+          __builtin_amdgcn_raw_buffer_store_b32((unsigned)cur_src, src_rs, fr_off + r * (unsigned)a.NT * 4u, 0, 0);
+        }
+        const unsigned zo = zs_off + r * (LAT * 4u);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{z[0], z[1], z[2], z[3]}), zs_rs, zo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{z[4], z[5], z[6], z[7]}), zs_rs, zo + 64u, 0, 0);
       }
-      if (m >= a.burnin && fvalid) {                    // mcem.py:435-437
-        if (STORE && q == 0) a.src[(size_t)(m - a.burnin) * a.NT + nrow] = cur_src;
-        float* dst = a.Zs + ((size_t)nrow * a.Rcap + (m - a.burnin)) * LAT;
-        *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{z[0], z[1], z[2], z[3]};
-        *reinterpret_cast<f32x4*>(dst + 16 + 4 * q) = f32x4{z[4], z[5], z[6], z[7]};
-      }
+      WC_STAMP(4);
     }
+    WC_STAMP_FLUSH;
     if (a.update_Z && fvalid) {                         // self.Z = last draw (mcem.py:466)
       float* dst = a.Z + (size_t)nrow * LAT;
       *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{z[0], z[1], z[2], z[3]};
@@ -494,3 +571,13 @@ int vn_launch_wchain(vaenmf_plan* p, const VnChainCall& cc, hipStream_t st) {
   VN_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+#ifdef VN_STAMP
+extern "C" int vaenmf_debug_stamps_wc(long long* out32, int reset) {
+  long long h[32];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wc_stamp), sizeof(h)) != hipSuccess) return -2;
+  for (int i = 0; i < 32; ++i) out32[i] = h[i];
+  if (reset) { long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wc_stamp), z, sizeof(z)); }
+  return 0;
+}
+#endif

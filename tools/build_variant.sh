@@ -10,7 +10,8 @@ srcs=${VN_VARIANT_SRCS:-"chain stream"}
 objs=""
 for s in engine chain aux plan labels stream; do
   if [[ " $srcs " == *" $s "* ]]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 "$@" -c $s.hip -o /tmp/${s}_$tag.o &
+    ff=""; [ $s = chain ] && ff="-fno-slp-vectorize"
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $ff "$@" -c $s.hip -o /tmp/${s}_$tag.o &
     objs="$objs /tmp/${s}_$tag.o"
   else
     objs="$objs $s.o"
