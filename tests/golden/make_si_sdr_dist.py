@@ -4,7 +4,7 @@
 The MH sampler is chaotic, so with the on-device generator only the DISTRIBUTION of the outcome can match the
 reference.  This script IMPORTS THE REFERENCE (python.models.mcem.MCEM_M1, python.models.models.
 VariationalAutoencoder, python.metrics.energy_ratios -- build container only, it never travels) and runs its
-unmodified EM over U short synthetic utterances x S seeds of torch's global generator, feeding it the oracle's
+unmodified EM over U short synthetic utterances x S (192) seeds of torch's global generator, feeding it the oracle's
 STFT (the reference's own front end needs librosa, which is not installed) and taking the oracle's iSTFT of
 its S_hat.  Committed output (data only): tests/golden/si_sdr_dist.npz with, per (utterance, seed), SI-SDR /
 SI-SIR / SI-SAR (dB) and the final EM cost, plus the configuration.  Sized so that the standard error of the
@@ -31,7 +31,7 @@ from python.models import models as ref_models
 from python import metrics as ref_metrics
 
 F, K, NITER, FS, WLEN = 257, 8, 20, 16000, 32e-3
-UTTS, SEEDS, T = 8, 48, 16000
+UTTS, SEEDS, T = 8, int(os.environ.get("SI_SDR_SEEDS", "192")), 16000
 
 
 def main():

@@ -1,62 +1,77 @@
-"""End-to-end statistical parity with the on-device generator (no replay): the MH sampler is
-chaotic, so trajectories cannot match the CPU path bit for bit; what must match is the
-distribution of the outcome.  Short synthetic utterances go through the WHOLE pipeline
-(STFT -> EM -> Wiener -> iSTFT -> SI-SDR) on the GPU in both precision modes and through the
-numpy oracle with several seeds each.
+"""End-to-end statistical parity with the on-device generator (no replay), against the REFERENCE itself.
 
-Stated tolerances: mean SI-SDR over (utterances x seeds): |GPU - oracle| <= 0.05 dB + 3 standard
-errors of the oracle's own seed-to-seed spread; final EM cost per utterance (mean over seeds):
-2e-3 relative (bf16: 1e-2) + 3 standard errors of the oracle's seed-to-seed spread of that mean."""
+The MH sampler is chaotic, so with the device generator trajectories cannot match the CPU path bit for bit;
+what must match is the distribution of the outcome.  tests/golden/si_sdr_dist.npz holds that distribution as
+produced by the imported reference (tests/golden/make_si_sdr_dist.py: MCEM_M1 unmodified, 8 synthetic
+utterances x 48 seeds of torch's generator, 20 EM iterations, Wiener chain, SI-SDR by python/metrics.py): per
+(utterance, seed) SI-SDR and final cost; the reference's own standard error of the mean SI-SDR over the set is
+0.008 dB.  Here the same utterances go through the WHOLE HIP pipeline (STFT -> EM -> Wiener -> iSTFT -> SI-SDR
+sums) with 48 device-generator seeds each, in every mode the engine offers -- the bench mode included (bf16 MFMA,
+sample variances stored as bf16 rows and streamed by the M-step).
+
+Stated tolerances, all derived from the seed-to-seed spreads themselves (no slack term):
+  mean SI-SDR over (utterances x seeds):  |GPU - reference| <= 3 sqrt(se_ref^2 + se_gpu^2)   (about 0.035 dB)
+  per utterance, mean over seeds:         |GPU - reference| <= 4 sqrt(se_ref_u^2 + se_gpu_u^2) (8 comparisons)
+  final EM cost per utterance, mean over seeds, relative: same 4-sigma rule on the relative spreads.
+The measured differences are printed (pytest -s) and quoted in DESIGN.md."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-import vaenmf_oracle as orc
+import vaenmf_oracle as orc      # synthetic utterances / seeded weights only (the generators shared with the fixture script)
 
-F, K, NITER, FS, WLEN = 257, 8, 12, 16000, 32e-3
-UTTS, SEEDS, T = 6, 3, 12000
-
-
-def oracle_run(x, s, n, params, seed):
-    X = orc.stft(x, fs=FS, wlen_sec=WLEN).T
-    m = orc.MCEMOracle("M1", NITER)
-    m.init_parameters(X, params, K, 1e-8, orc.NumpyRNG(seed))
-    cost = m.run()
-    s_hat = orc.istft(m.S_hat, fs=FS, wlen_sec=WLEN, max_len=len(x))
-    return orc.energy_ratios(s_hat.astype(np.float64), s, n)[0], cost[-1]
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_si_sdr_and_cost_distribution_match_oracle():
+def test_si_sdr_and_cost_distribution_match_reference():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from vaenmf.pipeline import Reconstructor
     from vaenmf import metrics as vm
+    z = np.load(os.path.join(HERE, "golden", "si_sdr_dist.npz"))
+    ref = z["results"]                                   # [U, S, 4]: si_sdr, si_sir, si_sar, final cost
+    F, K, NITER, FS, WLEN, T = int(z["F"]), int(z["K"]), int(z["niter"]), int(z["fs"]), float(z["wlen"]), int(z["T"])
+    U, S = ref.shape[:2]
     params = orc.xavier_normal_params([F, 32, [128, 128]], seed=0)
-    sig = [orc.synth_utterance(u, T) for u in range(UTTS)]
-    ref = np.array([[oracle_run(sig[u][2], sig[u][0], sig[u][1], params, 100 * u + sd) for sd in range(SEEDS)] for u in range(UTTS)])
+    sig = [orc.synth_utterance(u, T) for u in range(U)]
     dev = torch.device("cuda:0")
-    to_dev = lambda i: torch.from_numpy(np.concatenate([sg[i] for sg in sig]).astype(np.float32)).to(dev)
-    wav_x, wav_s, wav_n = to_dev(2), to_dev(0), to_dev(1)
+    # one batch = every (utterance, seed) pair: utterance u with seed sd sits at index sd * U + u
+    rep = lambda i: torch.from_numpy(np.concatenate([sg[i] for sg in sig] * S).astype(np.float32)).to(dev)
+    wav_x, wav_s, wav_n = rep(2), rep(0), rep(1)
     res = {}
-    # "bf16": the bench path (sample-variance store with bf16 rows feeding the M-step); "bf16 decode": the same
-    # precision with the M-step decoding the samples again
-    for name, prec, store in (("bf16x3", "bf16x3", None), ("bf16", "bf16", None), ("bf16 decode", "bf16", False)):
+    for name, prec, store in (("bf16x3", "bf16x3", None), ("bf16 + bf16 sample store (bench mode)", "bf16", None), ("bf16, M-step decoding", "bf16", False)):
         rec = Reconstructor(params, F, K, niter=NITER, fs=FS, wlen_sec=WLEN, precision=prec, device=dev,
-                            max_frames=UTTS * 120, max_utts=UTTS, store=store)
-        out = []
-        for sd in range(SEEDS):
-            s_hat, n_hat, cost = rec.enhance(wav_x, [T] * UTTS, seeds=[1000 * sd + u for u in range(UTTS)], init_seed=sd)
-            G = vm.gram3_batch(s_hat, wav_s, wav_n, [T] * UTTS)
-            out.append(np.stack([vm.ratios_from_gram(G)[0], cost[:, -1].cpu().numpy()], 1))
-        res[name] = np.stack(out, 1)                       # [U, SEEDS, 2]
-    sem = ref[:, :, 0].std(1, ddof=1).mean() / np.sqrt(UTTS * SEEDS)
-    csem = ref[:, :, 1].std(1, ddof=1) / np.abs(ref[:, :, 1].mean(1)) * np.sqrt(2.0 / SEEDS)   # rel. s.e. of a difference of means
-    for prec, ctol in (("bf16x3", 2e-3), ("bf16", 1e-2), ("bf16 decode", 1e-2)):
-        d_sdr = res[prec][:, :, 0].mean() - ref[:, :, 0].mean()
-        d_cost = np.abs(res[prec][:, :, 1].mean(1) / ref[:, :, 1].mean(1) - 1)
-        print("%s: mean SI-SDR gpu %.3f dB, oracle %.3f dB (diff %.3f, oracle seed sem %.3f); rel cost diff per utt %s (seed s.e. %s)"
-              % (prec, res[prec][:, :, 0].mean(), ref[:, :, 0].mean(), d_sdr, sem, np.round(d_cost, 4), np.round(csem, 4)))
-        assert abs(d_sdr) <= 0.05 + 3 * sem
-        assert np.all(d_cost <= ctol + 3 * csem)
+                            max_frames=U * S * (T // 128 + 8), max_utts=U * S, store=store)
+        s_hat, n_hat, cost = rec.enhance(wav_x, [T] * (U * S), seeds=[7919 * i + 13 for i in range(U * S)], init_seed=1)
+        G = vm.gram3_batch(s_hat, wav_s, wav_n, [T] * (U * S))
+        sdr = np.asarray(vm.ratios_from_gram(G)[0]).reshape(S, U).T                       # [U, S]
+        res[name] = np.stack([sdr, cost[:, -1].cpu().numpy().reshape(S, U).T], 2)           # [U, S, 2]
+        del rec
+    r_sdr, r_cost = ref[:, :, 0], ref[:, :, 3]
+    se_ref_u = r_sdr.std(1, ddof=1) / np.sqrt(S)
+    se_ref = np.sqrt(np.sum(se_ref_u ** 2)) / U
+    for name, g in res.items():
+        g_sdr, g_cost = g[:, :, 0], g[:, :, 1]
+        se_gpu_u = g_sdr.std(1, ddof=1) / np.sqrt(S)
+        se_gpu = np.sqrt(np.sum(se_gpu_u ** 2)) / U
+        d = g_sdr.mean() - r_sdr.mean()
+        tol = 3 * np.sqrt(se_ref ** 2 + se_gpu ** 2)
+        d_u = g_sdr.mean(1) - r_sdr.mean(1)
+        tol_u = 4 * np.sqrt(se_ref_u ** 2 + se_gpu_u ** 2)
+        rc = g_cost.mean(1) / r_cost.mean(1) - 1
+        tol_c = 4 * np.sqrt((r_cost.std(1, ddof=1) / r_cost.mean(1)) ** 2 + (g_cost.std(1, ddof=1) / g_cost.mean(1)) ** 2) / np.sqrt(S)
+        print("%s: mean SI-SDR gpu %.4f dB, reference %.4f dB: diff %+.4f dB (tolerance %.4f = 3 sigma; s.e. ref %.4f, gpu %.4f)\n"
+              "   per utterance diff (dB) %s  tol %s\n   relative final-cost diff %s  tol %s"
+              % (name, g_sdr.mean(), r_sdr.mean(), d, tol, se_ref, se_gpu, np.round(d_u, 3), np.round(tol_u, 3), np.round(rc, 5), np.round(tol_c, 5)))
+        assert abs(d) <= tol, (name, d, tol)
+        assert np.all(np.abs(d_u) <= tol_u), (name, d_u, tol_u)
+        assert np.all(np.abs(rc) <= tol_c), (name, rc, tol_c)
+    # paired: the bench mode against the parity-grade mode on the same device generator streams
+    a, b = res["bf16 + bf16 sample store (bench mode)"][:, :, 0], res["bf16x3"][:, :, 0]
+    dp = a - b
+    print("paired bf16+store - bf16x3 (same streams): mean %+.4f dB, s.e. %.4f dB" % (dp.mean(), dp.std(ddof=1) / np.sqrt(dp.size)))
+    assert abs(dp.mean()) <= 3 * dp.std(ddof=1) / np.sqrt(dp.size) + 1e-3
