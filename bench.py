@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- STFT-frames/s through the VAE-NMF reconstruct loop (BASELINE.json metric).
 
-A "step" is one pass of the whole hot path over one batch of synthetic utterances per
-GPU: waveforms resident in HBM -> STFT -> |X|^2 -> encoder -> 100 x (MH E-step, M-step)
--> Wiener chain + filter -> iSTFT -> SI-SDR sufficient statistics -> all-reduce of the
-metric statistics over ranks (the job's only collective).  Workload at N=1 =
-BASELINE.json configs[1]: 64 utterances x 4 s @16 kHz, 512-pt STFT (F=257, 501 frames
-each), M1, NMF rank 8, 100 EM iterations, reference-faithful MH counts (60/30 per
-E-step, 105/75 for the Wiener chain), decoder GEMMs on bf16 MFMA (fp32 accumulate; `--precision bf16x3`
-selects the 3-term split mode used for the tight parity tests, also timed once and reported as
-"parity_mode").  For N>1 every rank runs its own 64-utterance shard (weak scaling; utterances
-are independent).
+A "step" is one pass of the whole hot path over synthetic utterances resident in HBM:
+waveforms -> STFT -> |X|^2 -> encoder -> 100 x (MH E-step, M-step) -> Wiener chain + filter -> iSTFT ->
+SI-SDR sufficient statistics -> all-reduce of the metric statistics over ranks (the job's only collective).
 
-Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).
+  N = 1 (default)   BASELINE.json configs[1]: one 64-utterance batch per step (64 x 4 s @16 kHz, 512-pt STFT,
+                    F=257, 501 frames each, M1, NMF rank 8, 100 EM iterations, reference-faithful MH counts
+                    60/30 per E-step and 105/75 for the Wiener chain, bf16 decoder MFMAs with fp32 accumulate).
+  N > 1             BASELINE.json configs[3]: the fixed 1000-utterance synthetic set, split over the ranks exactly
+                    like scripts/evaluate_M1.py:203 (np.array_split), each rank working through its shard in
+                    batches of <= 64 (125 per GPU at N=8: 63 + 62); one step = the whole set; "scaling": "strong".
+                    `--total-utts 1000` runs the same job at N=1.
+
+`python bench.py --gpus N` starts the N ranks itself (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set, before anything touches the GPU) unless it already runs under a launcher (WORLD_SIZE set, e.g.
+torch.distributed.run), in which case --gpus must agree with WORLD_SIZE.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,56 +29,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "guided-vae-nmf_amd"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 PEAK_BF16_DENSE = 2.5e15     # FLOP/s, MI355X_MICROARCH.md (dense bf16 MFMA)
 PEAK_HBM = 8.0e12            # B/s spec (6.29e12 measured achievable)
+# transcendental issue on gfx950, measured (tools/ubench/trans16.hip): one v_exp/v_log/v_rcp_f32 wave-instruction
+# occupies its SIMD for 8.2 cycles, whatever the number of resident waves
+TRANS_CYCLES = 8.2
+BATCH = 64
 
 
-def algorithmic(F, N_frames, niter, nsE, biE, nsW, biW):
-    """minimal-pass bytes B_utt (fp32 sample tensor materialised once per
-    iteration) and decoder flops per frame."""
-    R, Rw = nsE, nsW
-    bytes_per_frame = niter * 4 * F * (5 * R + 6) + 4 * F * (5 * Rw + 6) + 24 * F
-    flop_row = 2 * (32 * 128 + 128 * 128 + 128 * F)
-    return bytes_per_frame, flop_row
-
-
-def cpu_baseline(F, n_frames, K, niter_full, sample_iters=12):
-    """Oracle (numpy restatement of the reference path, checker only) timed on the host
-    cores on a bounded sample: ONE utterance, `sample_iters` EM iterations + the Wiener
-    chain, per-iteration time extrapolated to niter_full."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import vaenmf_oracle as orc
-    from vaenmf.synth import synth_utterance
-    s, n, x, _ = synth_utterance(0)
-    X = orc.stft(x, fs=16000, wlen_sec=32e-3 if F == 257 else 64e-3, hop_percent=0.25).T
-    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=0)
-    m = orc.MCEMOracle("M1", sample_iters)
-    m.init_parameters(X, params, K, 1e-8, orc.NumpyRNG(0))
-    t0 = time.perf_counter()
-    for _ in range(sample_iters):
-        m.E_step(); m.M_step(); m.compute_expected_neg_log_like()
-    t_it = (time.perf_counter() - t0) / sample_iters
-    t0 = time.perf_counter()
-    m.compute_WF(sample=True)
-    t_wf = time.perf_counter() - t0
-    t_utt = t_it * niter_full + t_wf
-    cores = os.cpu_count() or 1
-    return {"value": X.shape[0] / t_utt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "numpy oracle, 1 utterance (%d frames, F=%d, K=%d): %d EM iterations + Wiener chain timed "
-                      "(%.3f s/iter, %.2f s WF), extrapolated to %d iterations; BLAS threads = host default"
-                      % (X.shape[0], F, K, sample_iters, t_it, t_wf, niter_full)}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--utts", type=int, default=64, help="utterances per GPU per step")
+    ap.add_argument("--utts", type=int, default=BATCH, help="utterances per batch (N=1 default workload: one batch per step)")
+    ap.add_argument("--total-utts", type=int, default=0,
+                    help="fixed utterance set sharded over the ranks (strong scaling; default 1000 when --gpus > 1)")
     ap.add_argument("--niter", type=int, default=100)
     ap.add_argument("--nfft", type=int, default=512)
     ap.add_argument("--rank-k", type=int, default=8)
@@ -81,153 +52,329 @@ def main():
                     help="decoder MFMA mode: bf16 (BASELINE config 2) or bf16x3 (3-term split, ~fp32 accuracy)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra bf16x3 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the one-step measurements of the other BASELINE configs")
     ap.add_argument("--force-store", action="store_true", help="sample store also in bf16x3 mode (float rows)")
     ap.add_argument("--no-store", action="store_true",
                     help="M-step / Wiener filter decode the samples again instead of streaming the chain's stored variances")
     ap.add_argument("--model", default="M1", choices=["M1", "M2vad", "M2ibm"],
                     help="M1 (BASELINE config 2, default) or the guided M2 variants of config 3 (labels from a classifier)")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend (gloo: CPU rehearsal of the launcher)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / sharding / all-reduce rehearsal without a GPU (tests): no hot path, synthetic statistics")
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def spawn_ranks(args):
+    """Start args.gpus child processes of this script, one per GPU; returns the exit code (non-zero if any rank failed)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VAENMF_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:                                              # a failed rank must never leave a half-reported run behind
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def note(msg):
+    """progress on stderr (stdout carries the one JSON line)"""
+    if os.environ.get("RANK", "0") == "0":
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def algorithmic(F, niter, nsE, nsW):
+    """minimal-pass bytes per frame B_utt / N (fp32 sample tensor materialised once per iteration) and
+    decoder flops per decoder row."""
+    bytes_per_frame = niter * 4 * F * (5 * nsE + 6) + 4 * F * (5 * nsW + 6) + 24 * F
+    flop_row = 2 * (32 * 128 + 128 * 128 + 128 * F)
+    return bytes_per_frame, flop_row
+
+
+def cpu_baseline(F, K, niter):
+    """The PyTorch-CPU restatement of EM.run (oracle/vaenmf_torch_cpu.py: float32 torch tensors, the reference's own
+    sequence of tensor operations, pinned by the reference-recorded golden runs) on BASELINE config 1: ONE 4 s
+    utterance, M1, `niter` EM iterations + Wiener chain, all host cores, median of 3 runs."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vaenmf_oracle as orc
+    import vaenmf_torch_cpu as tc
+    from vaenmf.synth import synth_utterance
+    # the GPU box gives one GPU's job 16 host cores; more torch threads than that only add synchronisation time
+    threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    torch.set_num_threads(threads)
+    s, n, x, _ = synth_utterance(0)
+    X = orc.stft(x, fs=16000, wlen_sec=32e-3 if F == 257 else 64e-3, hop_percent=0.25).T
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=0)
+    times = []
+    for rep in range(3):
+        m = tc.TorchMCEM("M1", niter)
+        m.init_parameters(X, params, K, 1e-8, tc.TorchDraws(rep))
+        t0 = time.perf_counter()
+        m.run()
+        times.append(time.perf_counter() - t0)
+        note("cpu baseline run %d: %.1f s" % (rep, times[-1]))
+    t = sorted(times)[1]
+    return {"value": X.shape[0] / t, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "PyTorch-CPU restatement of EM.run (oracle/vaenmf_torch_cpu.py), BASELINE config 1: 1 utterance (%d frames, "
+                      "F=%d, K=%d), %d EM iterations + Wiener chain, torch.set_num_threads(%d), median of 3 runs "
+                      "(%.2f / %.2f / %.2f s)" % (X.shape[0], F, K, niter, threads, *sorted(times))}
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))                     # before any GPU call
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d disagrees with WORLD_SIZE=%d" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from vaenmf.pipeline import shard, allreduce_stats
+    from vaenmf import metrics as vmet
+
+    if not args.dry_run and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if args.dry_run else torch.device("cuda", local_rank)
+    if not args.dry_run:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl" and not args.dry_run:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from vaenmf import _lib
-    from vaenmf.pipeline import Reconstructor, allreduce_stats
-    from vaenmf.synth import synth_utterance, xavier_normal_params
-    from vaenmf import metrics as vmet
-    import ctypes as C
-
+    total = args.total_utts or (1000 if world > 1 else 0)
+    strong = total > 0
     fs, nfft = 16000, args.nfft
     F = nfft // 2 + 1
-    wlen = nfft / fs
-    U, T = args.utts, 64000
-    # synthetic shard of this rank: utterance ids rank*U .. rank*U+U-1 (seeded, no dataset)
-    ids = [rank * U + i for i in range(U)]
-    base = {}
-    wav_x, wav_s, wav_n, snr = [], [], [], []
-    for uid in ids:
-        s, n, x, sdb = synth_utterance(uid % 16)        # 16 distinct signals, cycled (host generation time)
-        wav_x.append(x); wav_s.append(s); wav_n.append(n); snr.append(sdb)
-    to_dev = lambda l: torch.from_numpy(np.concatenate(l).astype(np.float32)).to(dev)
-    wav_x, wav_s, wav_n = to_dev(wav_x), to_dev(wav_s), to_dev(wav_n)
-    counts = [T] * U
-    Dy = {"M1": 0, "M2vad": 1, "M2ibm": F}[args.model]
-    params = xavier_normal_params([F, 32, [128, 128]], seed=0, y_dim=Dy)
-    clf = None
-    if Dy:
-        from vaenmf.synth import xavier_normal_classifier
-        cp = xavier_normal_classifier([F, [128, 128], Dy], seed=1)
-        clf = [(cp["hidden.0.weight"], cp["hidden.0.bias"]), (cp["hidden.1.weight"], cp["hidden.1.bias"]),
-               (cp["output_layer.weight"], cp["output_layer.bias"])]
-    rec = Reconstructor(params, F, args.rank_k, niter=args.niter, model="M1" if not Dy else "M2", reference_compat=True, fs=fs,
-                        wlen_sec=wlen, precision=args.precision, device=dev, max_frames=U * 520, max_utts=U,
-                        store=False if args.no_store else (True if args.force_store else None))
-    nsE, biE, nsW, biW = rec.nsE, rec.biE, rec.nsW, rec.biW
-
-    def step(i):
-        s_hat, n_hat, cost = rec.enhance(wav_x, counts, seeds=[1000 * i + u for u in ids], init_seed=i, classifier=clf)
-        G = vmet.gram3_batch(s_hat, wav_s, wav_n, counts)          # D2H of 6 doubles per utterance
-        r = np.stack(vmet.ratios_from_gram(G), 1)
-        st = allreduce_stats(vmet.sufficient_stats(r, snr), dev)   # RCCL all-reduce (<1 KB)
-        return st, cost
+    T = 64000
+    # utterance ids of this rank: the whole set split like scripts/evaluate_M1.py:203, or one batch
+    ids = [int(i) for i in shard(list(range(total)), world, rank)] if strong else [rank * args.utts + i for i in range(args.utts)]
+    nb = max(1, -(-len(ids) // BATCH))
+    batches = [list(b) for b in np.array_split(np.asarray(ids, dtype=np.int64), nb)] if ids else []   # 125 -> 63 + 62
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not args.dry_run:
+            torch.cuda.synchronize()
 
+    if args.dry_run:
+        # rehearsal of everything around the hot path: shard sizes, the statistics all-reduce, the max-over-ranks clock
+        snr = [[-5.0, 0.0, 5.0][i % 3] for i in ids]
+        r = np.stack([np.full(len(ids), -25.0), np.zeros(len(ids)), np.zeros(len(ids))], 1)
+        barrier()
+        t0 = time.perf_counter()
+        st = allreduce_stats(vmet.sufficient_stats(r, snr), dev)
+        barrier()
+        tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        cnt = torch.tensor([float(len(ids))], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "scaling": "strong" if strong else "weak", "utterances_total": int(cnt.item()),
+                              "utterances_rank0": len(ids), "batches_rank0": [len(b) for b in batches], "stats_count": float(st[0, 0, 0])}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    from vaenmf import _lib
+    from vaenmf.pipeline import Reconstructor
+    from vaenmf.synth import synth_utterance, xavier_normal_params, xavier_normal_classifier
+    import ctypes as C
+
+    base = [synth_utterance(k) for k in range(16)]          # 16 distinct signals, cycled (host generation time)
+    to_dev = lambda l: torch.from_numpy(np.concatenate(l).astype(np.float32)).to(dev)
+
+    def make_batch(b):
+        return (to_dev([base[u % 16][2] for u in b]), to_dev([base[u % 16][0] for u in b]), to_dev([base[u % 16][1] for u in b]),
+                [base[u % 16][3] for u in b], [T] * len(b))
+    data = [make_batch(b) for b in batches]
+    umax = max(len(b) for b in batches)
+
+    def make_rec(model, nfft_, K, precision, store, niter=None):
+        F_ = nfft_ // 2 + 1
+        Dy = {"M1": 0, "M2vad": 1, "M2ibm": F_}[model]
+        params = xavier_normal_params([F_, 32, [128, 128]], seed=0, y_dim=Dy)
+        clf = None
+        if Dy:
+            cp = xavier_normal_classifier([F_, [128, 128], Dy], seed=1)
+            clf = [(cp["hidden.0.weight"], cp["hidden.0.bias"]), (cp["hidden.1.weight"], cp["hidden.1.bias"]),
+                   (cp["output_layer.weight"], cp["output_layer.bias"])]
+        rec = Reconstructor(params, F_, K, niter=niter or args.niter, model="M1" if not Dy else "M2", reference_compat=True, fs=fs,
+                            wlen_sec=nfft_ / fs, precision=precision, device=dev, max_frames=umax * 520, max_utts=umax, store=store)
+        return rec, clf
+
+    store = False if args.no_store else (True if args.force_store else None)
+    rec, clf = make_rec(args.model, nfft, args.rank_k, args.precision, store)
+    nsE, biE, nsW, biW = rec.nsE, rec.biE, rec.nsW, rec.biW
+
+    def step(i, r=None, c=None, dd=None):
+        r, c, dd = r or rec, c if r else clf, dd or data
+        acc, cost = None, None
+        for bi, (wx, ws, wn, snr, counts) in enumerate(dd):
+            uids = batches[bi] if dd is data else list(range(len(counts)))
+            s_hat, n_hat, cost = r.enhance(wx, counts, seeds=[1000 * i + int(u) for u in uids], init_seed=i * 131 + bi, classifier=c)
+            G = vmet.gram3_batch(s_hat, ws, wn, counts)              # D2H of 6 doubles per utterance
+            st = vmet.sufficient_stats(np.stack(vmet.ratios_from_gram(G), 1), snr)
+            acc = st if acc is None else acc + st
+        return allreduce_stats(acc, dev), cost                       # RCCL all-reduce (<1 KB), once per step
+
+    note("workload ready: %d utterances on rank 0 in %d batch(es); warm-up" % (len(ids), len(batches)))
     for i in range(args.warmup):
         step(i)
-    n_launch = args.steps * (4 * args.niter + 8) + 16
-    _lib.check(_lib.lib().vaenmf_profile_enable(rec.eng._plan, n_launch))
     barrier()
+    note("timing %d step(s)" % args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
         st, cost = step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    note("timed region: %.1f ms per step" % (dt / args.steps * 1e3))
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    nutt = torch.tensor([float(len(ids))], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nutt, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    frames_per_utt = rec.frame_counts[0]
+    m_step_path = {1: "stored sample variances (rows written by the chain, streamed by the M-step and the Wiener filter)",
+                   2: "decode (the M-step decodes the samples again)"}.get(_lib.lib().vaenmf_plan_query(rec.eng._plan, _lib.Q_MSTEP_PATH), "?")
+
+    # ---- one more step OUTSIDE the timed region with per-launch HIP events on the launch stream (vaenmf_profile_*):
+    # kernel breakdown and the dominant kernel's average launch time
+    n_launch = len(data) * (4 * args.niter + 8) + 16
+    _lib.check(_lib.lib().vaenmf_profile_enable(rec.eng._plan, n_launch))
+    step(args.warmup + args.steps)
     ms = (C.c_double * 5)()
     cn = (C.c_int64 * 5)()
     _lib.check(_lib.lib().vaenmf_profile_read(rec.eng._plan, ms, cn))
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    _lib.check(_lib.lib().vaenmf_profile_enable(rec.eng._plan, 0))
 
-    # the same step in the bf16x3 (parity-grade) mode, one timed step, for the record
+    # ---- the other BASELINE configs, one timed step of one 64-utterance batch each (rank 0 of a 1-GPU run)
+    configs = []
     par = None
-    if args.precision == "bf16" and not args.no_parity_mode and world == 1 and not Dy:
+    if world == 1 and not strong and rank == 0:
         del rec
         torch.cuda.empty_cache()
-        rec3 = Reconstructor(params, F, args.rank_k, niter=args.niter, model="M1", reference_compat=True, fs=fs,
-                             wlen_sec=wlen, precision="bf16x3", device=dev, max_frames=U * 520, max_utts=U)
-        rec3.enhance(wav_x, counts, seeds=[u for u in ids], init_seed=0)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        rec3.enhance(wav_x, counts, seeds=[7 + u for u in ids], init_seed=1)
-        torch.cuda.synchronize()
-        t3 = time.perf_counter() - t1
-        par = {"dtype": "bf16x3", "value": U * rec3.frame_counts[0] / t3, "unit": "frames/s", "ms_per_step": t3 * 1e3}
-        rec = rec3
+        b64 = [make_batch(list(range(BATCH)))]
+        umax = BATCH
+        todo = []
+        if not args.no_parity_mode and args.precision == "bf16" and args.model == "M1":
+            todo.append(("parity-grade mode: config 2 in bf16x3 (3-term split products)", "M1", nfft, args.rank_k, "bf16x3", None))
+        if not args.no_configs:
+            todo += [("config 3: M2 guided, VAD label (y_dim 1) from a classifier", "M2vad", 512, 8, args.precision, None),
+                     ("config 3: M2 guided, IBM labels (y_dim F) from a classifier", "M2ibm", 512, 8, args.precision, None),
+                     ("reference scripts' STFT: 1024-pt (F=513), rank 10", "M1", 1024, 10, args.precision, None),
+                     ("config 5 shape (stress): 1024-pt STFT, rank 32 (100 of its 500 iterations)", "M1", 1024, 32, args.precision, None)]
+        for name, model, nf, K, prec, st_ in todo:
+            note("one step of: " + name)
+            r2, c2 = make_rec(model, nf, K, prec, st_)
+            step(0, r2, c2, b64)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, cst = step(1, r2, c2, b64)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter() - t1
+            e = {"name": name, "dtype": prec, "frames_per_s": BATCH * r2.frame_counts[0] / t2, "ms_per_step": t2 * 1e3,
+                 "final_cost_mean": float(cst[:, -1].mean().item()),
+                 "m_step_path": {1: "stored", 2: "decode"}.get(_lib.lib().vaenmf_plan_query(r2.eng._plan, _lib.Q_MSTEP_PATH), "?")}
+            if name.startswith("parity-grade"):
+                par = {"dtype": "bf16x3", "value": e["frames_per_s"], "unit": "frames/s", "ms_per_step": e["ms_per_step"], "m_step_path": e["m_step_path"]}
+            else:
+                configs.append(e)
+            del r2
+            torch.cuda.empty_cache()
+
     if rank == 0:
-        frames_per_utt = rec.frame_counts[0]
-        frames = U * frames_per_utt * world * args.steps
+        n_total = int(nutt.item())
+        frames = n_total * frames_per_utt * args.steps
         value = frames / dt
-        bpf, flop_row = algorithmic(F, frames_per_utt, args.niter, nsE, biE, nsW, biW)
-        # dominant kernel = mh_chain: algorithmic decoder flops per launch / avg launch time
+        bpf, flop_row = algorithmic(F, args.niter, nsE, nsW)
         chain_ms = ms[0] / max(cn[0], 1)
-        rows_e = U * frames_per_utt * (nsE + biE)                  # one proposal decode per MH step
-        rows_w = U * frames_per_utt * (nsW + biW)
-        n_e = args.niter * args.steps
-        n_w = args.steps
-        flops_chain_avg = flop_row * (rows_e * n_e + rows_w * n_w) / max(n_e + n_w, 1)
-        achieved = flops_chain_avg / (chain_ms * 1e-3) / 1e12 if chain_ms > 0 else 0.0
-        # HBM bytes of the chain kernel per launch from the committed rocprofv3 PMC passes of this command
-        # (profiles/round1_<precision>_traffic.json; collected with tools/profile.sh), else null
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "round1_%s_traffic.json" % args.precision)))
-            traffic = [v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items() if k.startswith("mh_chain_kernel")][0]
-        except Exception:
-            pass
+        rows_per_launch = []
+        for (_, _, _, _, counts) in data:
+            rows_per_launch += [len(counts) * frames_per_utt * (nsE + biE)] * args.niter + [len(counts) * frames_per_utt * (nsW + biW)]
+        rows_avg = float(np.mean(rows_per_launch))
+        achieved = flop_row * rows_avg / (chain_ms * 1e-3) / 1e12 if chain_ms > 0 else 0.0
+        # transcendental-issue roofline of the chain: per decoder row 256 tanh (exp + rcp) and F bins (exp, 1/2 log, 1/2 rcp)
+        trans_per_row = 2 * 256 + 2 * F
+        t_trans = trans_per_row * rows_avg / 64.0 * TRANS_CYCLES / (1024 * 2.4e9)      # 1024 SIMDs at the 2.4 GHz peak clock
+        traffic, traffic_src = None, None
+        for cand in ("round2_%s_traffic.json" % args.precision, "round1_%s_traffic.json" % args.precision):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                traffic = [v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items() if "chain_kernel" in k][0]
+                traffic_src = "profiles/" + cand
+                break
+            except Exception:
+                pass
         kernels = {k: {"ms_total": round(ms[i], 3), "launches": int(cn[i])}
                    for i, k in enumerate(["mh_chain", "m_wstats", "w_update", "m_hg", "wiener"])}
+        iter_ms = sum(ms[i] / max(cn[i], 1) for i in range(4))
+        workload = (("fixed %d-utterance set sharded over %d GPU(s) in batches of <= %d" % (n_total, world, BATCH)) if strong
+                    else ("%d-utterance batch per GPU" % args.utts))
         out = {
             "metric": "STFT-frames/sec through VAE-NMF reconstruct loop; SI-SDR parity vs ref",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "bf16x3 (bf16 MFMA, 3-term hi/lo split, fp32 accumulate)" if args.precision == "bf16x3" else "bf16",
             "data": "synthetic",
-            "config": {"workload": ("%d-utterance batch per GPU, %s reconstruct, %d-pt STFT (F=%d, %d frames/utt), "
-                                    "NMF rank %d, %d EM iters, MH %d/%d per E-step + %d/%d Wiener chain")
-                                   % (U, args.model, nfft, F, frames_per_utt, args.rank_k, args.niter, nsE + biE, nsE, nsW + biW, nsW),
-                       "utterances_per_gpu": U, "parallelism": "utterance-shard x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "mh_chain_kernel", "achieved": achieved, "peak": PEAK_BF16_DENSE / 1e12,
+            "config": {"workload": "%s, %s reconstruct, %d-pt STFT (F=%d, %d frames/utt), NMF rank %d, %d EM iters, MH %d/%d per E-step + %d/%d Wiener chain"
+                                   % (workload, args.model, nfft, F, frames_per_utt, args.rank_k, args.niter, nsE + biE, nsE, nsW + biW, nsW),
+                       "utterances_total": n_total, "utterances_rank0": len(ids), "batches_rank0": [len(b) for b in batches],
+                       "parallelism": "utterance-shard x%d (np.array_split, no collective in the loop)" % world},
+            "roofline": {"bound": "mfma", "kernel": "wchain_kernel (MH chain)", "achieved": achieved, "peak": PEAK_BF16_DENSE / 1e12,
                          "unit": "TFLOP/s", "frac": achieved * 1e12 / PEAK_BF16_DENSE, "traffic": traffic,
+                         "traffic_source": ("%s (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this command; not measured in this run)" % traffic_src) if traffic_src else None,
                          "avg_launch_ms": chain_ms,
-                         "note": "algorithmic decoder flops (1 proposal decode per MH step, %d flop/row); the bf16x3 mode "
-                                 "issues 3 MFMAs per algorithmic product" % flop_row},
-            "hbm_equiv": {"algorithmic_bytes_per_frame": bpf, "achieved_GBps": value * bpf / 1e9,
-                          "frac_of_8TBps": value * bpf / PEAK_HBM,
-                          "note": "SURVEY 8(d) B_utt credit (fp32 sample variances written once, read twice per iteration)"},
-            "m_step_path": ("decode" if (args.no_store or args.precision != "bf16") else
-                            "stored sample variances (bf16 rows written by the chain, streamed by the M-step and the Wiener filter)"),
+                         "note": "algorithmic decoder flops (1 proposal decode per MH step, %d flop/row) / HIP-event launch time of a "
+                                 "profiled step outside the timed region; the bf16x3 mode issues 3 MFMAs per algorithmic product" % flop_row,
+                         "valu_issue": {"transcendentals_per_row": trans_per_row, "cycles_per_wave_instruction": TRANS_CYCLES,
+                                        "floor_ms": t_trans * 1e3, "frac": t_trans * 1e3 / chain_ms if chain_ms > 0 else None,
+                                        "note": "the kernel's real bound: v_exp/v_log/v_rcp_f32 issue (8.2 cycles per wave-instruction "
+                                                "per SIMD, no overlap between resident waves; 1024 SIMDs, 2.4 GHz)"}},
+            "hbm_equiv": {"algorithmic_bytes_per_frame": bpf, "achieved_GBps": value * bpf / 1e9, "frac_of_8TBps": value * bpf / PEAK_HBM,
+                          "note": "SURVEY 8(d) B_utt CREDIT (fp32 sample variances written once, read by W-, H-, g-update and cost per "
+                                  "iteration); the build moves fewer real bytes -- see measured_hbm"},
+            "m_step_path": m_step_path,
             "kernels": kernels,
             "si_sdr_mean_db": float(st[0, 0, 1] / max(st[0, 0, 0], 1)),
             "final_cost_mean": float(cost[:, -1].mean().item()),
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(F, frames_per_utt, args.rank_k, args.niter)
+        try:        # real HBM bytes per EM iteration from the committed PMC passes, against the measured iteration time
+            tj = json.load(open(os.path.join(ROOT, "profiles", traffic_src.split("/", 1)[1])))
+            per_iter = sum(v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()
+                           if any(s in k for s in ("chain_kernel", "wstats_stream", "hg_stream", "w_partial", "w_update")))
+            out["measured_hbm"] = {"bytes_per_em_iteration": per_iter, "GBps": per_iter / (iter_ms * 1e-3) / 1e9,
+                                   "frac_of_8TBps": per_iter / (iter_ms * 1e-3) / PEAK_HBM,
+                                   "note": "rocprofv3 PMC bytes (committed profile, not this run) / this run's kernel time per EM iteration"}
+        except Exception:
+            pass
+        if configs:
+            out["configs"] = configs
         if par is not None:
             out["parity_mode"] = par
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(F, args.rank_k, args.niter)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

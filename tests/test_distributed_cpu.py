@@ -62,3 +62,43 @@ def test_shard_and_allreduce_world2():
         assert np.allclose(r[2], ref) and r[3] == 6.0
     tab = vm.stats_table(res[0][2])
     assert tab[("all", "SI-SDR")][2] == 11
+
+
+def _run_bench(extra, env=None):
+    import json
+    import subprocess
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=e, capture_output=True, text=True, timeout=300)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, ([json.loads(l) for l in lines]), p.stderr
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`bench.py --gpus N` must run N ranks or fail: here N=2 over gloo on the CPU, in the rehearsal mode that does
+    everything but the hot path (spawn with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*, the fixed 1000-utterance set split
+    like scripts/evaluate_M1.py:203, batches of <= 64, the statistics all-reduce, one JSON line from rank 0)."""
+    rc, out, err = _run_bench(["--gpus", "2", "--dry-run", "--backend", "gloo"])
+    assert rc == 0, err[-2000:]
+    assert len(out) == 1
+    o = out[0]
+    assert o["n_gpus"] == 2 and o["scaling"] == "strong" and o["utterances_total"] == 1000 and o["utterances_rank0"] == 500
+    assert o["batches_rank0"] == [63, 63, 63, 63, 62, 62, 62, 62] and o["stats_count"] == 1000
+    # 8 ranks of the real run: 125 utterances per GPU in waves of 63 + 62
+    sys.path.insert(0, os.path.join(ROOT, "guided-vae-nmf_amd"))
+    from vaenmf.pipeline import shard
+    mine = shard(list(range(1000)), 8, 3)
+    assert len(mine) == 125 and mine[0] == 375
+    assert [len(b) for b in np.array_split(np.asarray(mine), 2)] == [63, 62]
+
+
+def test_bench_refuses_a_world_size_that_disagrees():
+    rc, out, err = _run_bench(["--gpus", "8", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and not out and "disagrees" in err
+
+
+def test_bench_single_rank_dry_run():
+    rc, out, err = _run_bench(["--dry-run"])
+    assert rc == 0 and out[0]["n_gpus"] == 1 and out[0]["scaling"] == "weak" and out[0]["utterances_total"] == 64

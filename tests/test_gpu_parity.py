@@ -322,6 +322,27 @@ def test_stft_istft_and_metrics():
     assert np.allclose(r, zz["a_ratios"], atol=1e-6)
 
 
+def test_stft_against_reference_known_answer():
+    """The HIP STFT against the reference's OWN committed output (data/subset/pickle/CSR-1-WSJ-0/si_et_05_frames.p,
+    |stft(x)|^2 of its raw utterance 440c020a; fixture tests/golden/stft_frames.npz, extracted without unpickling):
+    first / last 96 frames and every frame's sum over the bins, same bounds as the oracle's CPU test."""
+    need_gpu()
+    from vaenmf import stft as vstft
+    z = np.load(GOLDEN + "/stft_frames.npz")
+    x = z["pcm_a"].astype(np.float64) / 32768.0
+    x = x[int(0.1 * 16000):]
+    x = x / np.max(np.abs(x))                                       # tests/dataset/test_csr1_wjs0_dataset.py:40-47
+    X = vstft.stft(x, fs=16000, wlen_sec=64e-3, win="hann", hop_percent=0.25)
+    P = np.power(np.abs(X), 2)
+    n0 = int(z["frame_counts"][0])
+    assert P.shape == (513, n0)
+    scale = np.max(z["head"])
+    assert np.max(np.abs(P[:, :96] - z["head"])) < 2e-7 * scale and np.max(np.abs(P[:, n0 - 96:] - z["tail"])) < 2e-7 * scale
+    big = z["head"] > 1e-6 * scale
+    assert np.max(np.abs(P[:, :96][big] / z["head"][big] - 1)) < 1e-5
+    assert np.max(np.abs(P.sum(0, dtype=np.float64) / z["col_sums"] - 1)) < 1e-6
+
+
 @pytest.mark.parametrize("F,K,R,model", [(513, 10, 30, "M1"), (513, 32, 10, "M2"), (257, 32, 30, "M1"), (129, 16, 40, "M1")])
 def test_m_step_and_chain_other_shapes(F, K, R, model):
     """M-step (mcem.py:90-152) + cost + one MH chain + Wiener filter at the shapes the golden runs do not
@@ -632,7 +653,8 @@ def test_sample_store_holds_the_samples_variances():
             eng.sample_store(False)
 
 
-@pytest.mark.parametrize("F,K,prec", [(257, 8, "bf16x3"), (257, 8, "bf16"), (513, 10, "bf16x3"), (65, 4, "bf16x3"), (257, 32, "bf16")])
+@pytest.mark.parametrize("F,K,prec", [(257, 8, "bf16x3"), (257, 8, "bf16"), (513, 10, "bf16x3"), (65, 4, "bf16x3"), (257, 32, "bf16"),
+                                       (513, 32, "bf16"), (513, 32, "bf16x3")])   # the last two: BASELINE config 5 (stress) instantiations
 def test_stored_m_step_and_wiener_match_the_decoding_ones(F, K, prec):
     """vaenmf_m_step_stored / vaenmf_wiener_stored (streaming the chain's stored variances) against
     vaenmf_m_step / vaenmf_wiener (decoding Zs again) from the same state and the same chain: the same W, H, g,
@@ -677,6 +699,56 @@ def test_stored_m_step_and_wiener_match_the_decoding_ones(F, K, prec):
         assert float((WFsa[:, :F] - WFsb[:, :F]).abs().max()) < tw and float((WFna[:, :F] - WFnb[:, :F]).abs().max()) < tw
         assert nrm_err(Sb.cpu().numpy(), Sa.cpu().numpy()) < tw and nrm_err(Nb.cpu().numpy(), Na.cpu().numpy()) < tw
         assert float(Sb[:, F:].abs().max()) == 0.0 and float(WFsb[:, F:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("variant", ["m2_labels", "nonmf_gains_only"])
+def test_stored_path_with_labels_and_fixed_noise(variant):
+    """The streaming M-step / Wiener filter in the two configurations the parametrised test above does not reach:
+    M2 (per-frame layer-1 bias B1 from the labels, mcem.py:242) and the *_noNMF variants (fixed noise variance, gains
+    only, mcem.py:543-578), bf16 mode, against the decoding kernels from the same chain."""
+    need_gpu()
+    F, K, Dy = 257, 8, 1
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=4, y_dim=Dy if variant == "m2_labels" else 0, bias_std=0.1)
+    counts, seeds = [37, 64, 70], [5, 6, 7]
+    g = np.random.default_rng(9)
+    Xs = [((g.standard_normal((n, F)) + 1j * g.standard_normal((n, F))) * (1 + 3 * np.exp(-np.arange(F) / 40.0))).astype(np.complex64) for n in counts]
+    W0 = [np.maximum(g.random((F, K)), 1e-8).astype(np.float32) for _ in counts]
+    H0 = [np.maximum(g.random((K, n)), 1e-8).astype(np.float32) for n in counts]
+    y = torch.from_numpy((g.random((sum(counts), Dy)) > 0.5).astype(np.float32))
+
+    def prep():
+        eng = make_engine(params, F, K, counts, Rcap=12, seeds=seeds, precision="bf16")
+        eng.set_spectrogram(Xs)
+        eng.init_nmf(W0, H0)
+        if variant == "m2_labels":
+            eng.set_labels(y.cuda())
+        else:
+            Vb = torch.zeros(eng.NT, eng.Fs, device="cuda")
+            Vb[:, :F] = torch.from_numpy(g.random((sum(counts), F)).astype(np.float32) + 0.1).cuda()
+            eng.set_noise_psd(Vb)
+        eng.sample_store(True)
+        return eng
+
+    g = np.random.default_rng(10)          # (both engines draw the same noise PSD)
+    ea = prep()
+    g = np.random.default_rng(10)
+    eb = prep()
+    for it in range(2):
+        for e in (ea, eb):
+            e.mh_chain(10, 4, 0.01, call=it)
+        assert torch.equal(ea.Zs, eb.Zs)
+        ca, cb = ea.m_step(10).clone(), eb.m_step_stored().clone()
+        for name in ("W", "Ht", "g"):
+            x, yv = getattr(ea, name).cpu().numpy(), getattr(eb, name).cpu().numpy()
+            assert np.max(np.abs(x - yv) / (np.abs(x) + 1e-20)) < 1e-2, (name, it)
+        assert np.max(np.abs(ca.cpu().numpy() - cb.cpu().numpy()) / np.abs(ca.cpu().numpy())) < 5e-4
+        for name in ("W", "Ht", "g"):
+            getattr(eb, name).copy_(getattr(ea, name))
+    for e in (ea, eb):
+        e.mh_chain(10, 4, 0.01, call=9, update_Z=False)
+    Sa, Na, _, _ = ea.wiener(10)
+    Sb, Nb, _, _ = eb.wiener_stored()
+    assert nrm_err(Sb.cpu().numpy(), Sa.cpu().numpy()) < 1e-2 and nrm_err(Nb.cpu().numpy(), Na.cpu().numpy()) < 1e-2
 
 
 def test_fused_run_with_the_sample_store():

@@ -159,3 +159,51 @@ def test_spp_estimator_against_reference():
         assert np.array_equal(orc.timo_mask_estimation(P), z["mask%d" % u])
         assert np.array_equal(orc.timo_vad_estimation(P), z["vad%d" % u])
         assert np.array_equal(orc.timo_noise_estimation(P, z["mask%d" % u]), z["psd%d" % u])
+
+
+def _stft_fixture_power():
+    """|STFT|^2 of the reference's raw utterance 440c020a as tests/dataset/test_csr1_wjs0_dataset.py:40-66 prepares it
+    (drop the first 0.1 s, divide by the peak), with the oracle's STFT; and the reference's own values for it."""
+    z = np.load(os.path.join(GOLDEN, "stft_frames.npz"))
+    x = z["pcm_a"].astype(np.float64) / 32768.0                     # sf.read of 16-bit PCM
+    x = x[int(0.1 * 16000):]
+    x = x / np.max(np.abs(x))
+    return z, x
+
+
+def test_stft_against_reference_known_answer():
+    """STFT pinned against the reference's OWN committed output: data/subset/pickle/CSR-1-WSJ-0/si_et_05_frames.p
+    (extracted without unpickling by tests/golden/extract_ref_pickles.py) holds |stft(x)|^2 produced by the reference
+    (python/processing/stft.py:16-63 -> librosa).  First / last 96 frames (reflect padding at both ends, end-pad rule)
+    and the per-frame sums over the bins of every frame."""
+    z, x = _stft_fixture_power()
+    X = orc.stft(x, fs=16000, wlen_sec=64e-3, win="hann", hop_percent=0.25)
+    P = np.power(np.abs(X), 2)
+    n0 = int(z["frame_counts"][0])
+    assert P.shape == (513, n0)
+    scale = np.max(z["head"])
+    assert np.max(np.abs(P[:, :96] - z["head"])) < 2e-7 * scale and np.max(np.abs(P[:, n0 - 96:] - z["tail"])) < 2e-7 * scale
+    big = z["head"] > 1e-6 * scale
+    assert np.max(np.abs(P[:, :96][big] / z["head"][big] - 1)) < 5e-6
+    assert np.max(np.abs(P.sum(0, dtype=np.float64) / z["col_sums"] - 1)) < 1e-6
+
+
+@pytest.mark.parametrize("name,model", CASES)
+def test_torch_cpu_restatement_full_run(name, model):
+    """oracle/vaenmf_torch_cpu.py (the PyTorch-CPU program timed as bench.py's cpu_baseline) against the
+    reference-recorded runs: same draws in the same order, same cost trajectory, same outputs."""
+    import torch
+    import vaenmf_torch_cpu as tc
+    torch.set_num_threads(1)
+    z, params, draws, meta = load_case(name)
+    nsE, biE, nsW, biW = meta["counts"]
+    m = tc.TorchMCEM(model, meta["niter"], nsE, biE, nsW, biW, 0.01, reference_compat=True)
+    rng = tc.ReplayDraws(draws)
+    m.init_parameters(z["X"], params, meta["K"], 1e-8, rng, y=z["y"] if model == "M2" else None)
+    assert np.max(np.abs(m.Z.numpy() - z["Z0"])) < 2e-5
+    cost = m.run()
+    assert rng.pos == len(rng.draws)
+    assert np.max(np.abs(cost - z["cost"]) / np.abs(z["cost"])) < 2e-5
+    for k, v in (("W", m.W), ("H", m.H), ("g", m.g)):
+        assert rel_err(v.numpy(), z[k]) < 2e-4, k
+    assert nrm_err(m.S_hat, z["S_hat"]) < 1e-5 and nrm_err(m.N_hat, z["N_hat"]) < 1e-5
