@@ -21,10 +21,19 @@
 #ifndef VN_WS_WAVES
 #define VN_WS_WAVES 4
 #endif
+#ifndef VN_ROWGRP
+#define VN_ROWGRP 6     // rows whose arithmetic the scheduler may interleave in the exact-count stream kernels
+#endif
+#ifndef VN_STREAM2
+#define VN_STREAM2 1      // frame-pipelined W-statistics / H,g kernels (dev builds: 0 = the batch-at-a-time forms)
+#endif
 
 int vn_ensure_dyn_lds(const void* fn, int bytes);     // plan.hip
 
 namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 struct StreamArgs {
   const void* VsS;             // [NT][Rs][Fs], float or bf16 (template ST)
@@ -37,6 +46,7 @@ struct StreamArgs {
   int gains_only;              // the *_noNMF M-step (mcem.py:543-578): Vb given, only g moves
   int store_f32;               // rows are float (bf16x3 mode) rather than bf16
   int w_blk_lds;               // rank > 8: W of the workgroup's first utterance is staged in LDS
+  int n_sms;
 };
 
 __device__ __forceinline__ float wave_sum(float v) { return sum_rows4(sum_row16(v)); }
@@ -178,27 +188,73 @@ struct FrameCtx {
 // the batch is issued before the first use, so a wavefront keeps RB x 0.5-1 KiB in flight -- the kernels are
 // latency-bound otherwise (86 % of the wave time in s_waitcnt with 4 loads in flight) -- and the H / g / cost
 // passes of hg_stream reuse the registers instead of reading the rows again when the frame fits one batch.
-template <int NCH, typename ST, int DIV = 1>
+// RT > 0: the frame has exactly RT rows (compile time: the row loops carry no checks, so the compiler interleaves the
+// rows' dependent chains); RT = 0: any row count up to RB (one uniform branch per row).
+template <int NCH, typename ST, int DIV = 1, int RT = 0>
 struct RowBatch {
   static constexpr int RB = (sizeof(ST) == 2 ? 32 : 16) / NCH / DIV;
+  static_assert(RT <= RB, "RT");
+  __device__ __forceinline__ bool on(int r) const { return RT > 0 ? r < RT : r < nr; }
   using raw_t = typename std::conditional<sizeof(ST) == 4, f32x4, bf16x4>::type;
   raw_t raw[RB][NCH];
   float xr;                    // lane j: extra bin (F-1) of row j of the batch
   int nr;
   // rows r0 .. r0+nr-1 of the frame whose store block starts at `base`; scol = the frame's column of the
   // sample-major slot map (stride NT)
+  // lane j: slot of row r0 + j of the frame (the frame's column of the sample-major slot map, stride NT)
   template <typename FC>
-  __device__ __forceinline__ void load(const FC& fc, const ST* base, const int32_t* scol, int r0, int R) {
-    nr = R - r0 < RB ? R - r0 : RB;
-    const int sl = scol[(size_t)(r0 + (fc.lane < nr ? fc.lane : 0)) * fc.a.NT];
+  static __device__ __forceinline__ int load_slots(const FC& fc, const int32_t* scol, int r0, int R) {
+    const int nr_ = R - r0 < RB ? R - r0 : RB;
+    return scol[(size_t)(r0 + (fc.lane < nr_ ? fc.lane : 0)) * fc.a.NT];
+  }
+  // rows r0 .. r0+nr-1 of the frame whose store block starts at `base`, slots from load_slots
+  template <typename FC>
+  __device__ __forceinline__ void load_rows(const FC& fc, const ST* base, int sl, int r0, int R) {
+    nr = RT > 0 ? RT : (R - r0 < RB ? R - r0 : RB);
     xr = fc.has_x ? (float)base[(size_t)sl * fc.a.Fs + fc.a.F - 1] : 0.f;
 #pragma unroll
     for (int r = 0; r < RB; ++r)
-      if (r < nr) {
+      if (on(r)) {
         const ST* row = base + (size_t)__builtin_amdgcn_readlane(sl, r) * fc.a.Fs;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) raw[r][c] = *reinterpret_cast<const raw_t*>(row + (fc.cv[c] ? fc.f0[c] : 0));
       }
+  }
+  template <typename FC>
+  __device__ __forceinline__ void load(const FC& fc, const ST* base, const int32_t* scol, int r0, int R) {
+    load_rows(fc, base, load_slots(fc, scol, r0, R), r0, R);
+  }
+  // The same through a buffer resource over the whole store (below 4 GB): a row's address is the resource (SGPRs) +
+  // this lane's constant byte offset (one VGPR) + a scalar offset built from the row's slot -- no 64-bit address
+  // pair per row in vector registers (thirty of them per frame spilled in the pipelined kernels).
+  template <typename FC>
+  __device__ __forceinline__ void load_rows_buf(const FC& fc, __amdgpu_buffer_rsrc_t rs, unsigned frame_off, int sl, int R) {
+    nr = RT > 0 ? RT : (R < RB ? R : RB);
+    const unsigned rowb = (unsigned)fc.a.Fs * (unsigned)sizeof(ST);
+    if (fc.has_x) {
+      const unsigned o = frame_off + (unsigned)sl * rowb + (unsigned)(fc.a.F - 1) * (unsigned)sizeof(ST);
+      if constexpr (sizeof(ST) == 2) xr = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, o, 0, 0) << 16);
+      else xr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0));
+    } else xr = 0.f;
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+      if (on(r)) {
+        const unsigned so = frame_off + (unsigned)__builtin_amdgcn_readlane(sl, r) * rowb;       // uniform
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const unsigned vo = (unsigned)(fc.cv[c] ? fc.f0[c] : 0) * (unsigned)sizeof(ST);
+          if constexpr (sizeof(ST) == 2) raw[r][c] = __builtin_bit_cast(raw_t, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0));
+          else raw[r][c] = __builtin_bit_cast(raw_t, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
+        }
+      }
+  }
+  // Between two passes over the same batch: without this the compiler keeps the UNPACKED floats of the first pass
+  // alive for the next one (common-subexpression elimination of the bf16 -> float conversions: 120 registers).
+  __device__ __forceinline__ void repack() {
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(raw[r][c]));
   }
   __device__ __forceinline__ void get(int r, f32x4 (&v)[NCH]) const {     // r: compile-time after unrolling
 #pragma unroll
@@ -600,10 +656,290 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Frame-pipelined forms (the frame's samples fit one register batch: R <= RowBatch::RB).  Two wavefronts per SIMD
+// with 256 registers each instead of four with 128: a wavefront holds TWO batches, the frame it computes on and the
+// NEXT frame's rows, requested in full before the first arithmetic instruction of the current frame.  Nothing in
+// the frame body waits on vmcnt except for operands requested a whole frame earlier, there is no spill (a scratch
+// reload would wait, through the in-order vmcnt, for the thirty row loads in flight), and every wavefront has
+// 15 KB of loads outstanding all the time.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NCH, int KP>
+struct FrameSmall {            // the per-frame operands besides the rows, requested one frame ahead like the rows
+  f32x4 x2[NCH];
+  float x2x, g;
+  float h[KP];
+  int utt;
+};
+
+template <int NCH, int KP, typename ST, int RT>
+__global__ __launch_bounds__(256, 2) void wstats_stream2_kernel(const StreamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  FrameCtx<NCH, KP, ST> fc(a, wlds + (KP <= 8 ? (size_t)(threadIdx.x >> 6) * a.Fs * KP : 0));
+  fc.stage_block_w();
+  using RBt = RowBatch<NCH, ST, 1, RT>;
+  using FS = FrameSmall<NCH, KP>;
+  int n_beg, n_end;
+  wave_frames(a.NT, n_beg, n_end);
+  if (n_beg >= n_end) return;
+  __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.VsS), 0, (int)((unsigned)a.NT * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST)), 0x00020000);
+  // slots are requested TWO frames ahead, rows and operands one frame ahead: the row addresses depend on the slots,
+  // and a wait for the slots placed between two frames' row loads would expose a full memory round trip per frame
+  auto request = [&](int n, RBt& rb, FS& s, int sl) {
+    s.utt = a.frame_utt[n];
+    s.g = a.g[n];
+#pragma unroll
+    for (int k = 0; k < KP; k += 4) {
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s.h[k + t] = hv[t];
+    }
+    fc.load_x2(n, s.x2, s.x2x);
+    rb.load_rows_buf(fc, vrs, (unsigned)n * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST), sl, a.R);
+  };
+  auto compute = [&](int n, const RBt& rb, const FS& s) {
+    fc.set_utt(s.utt);
+    f32x4 vb[NCH], a1[NCH], a2[NCH];
+    float vbx, a1x = 0.f, a2x = 0.f;
+    fc.noise_var(s.utt, s.h, vb, vbx);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) a1[c] = a2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < RBt::RB; ++r) {
+      if (RT > 0 && (r % VN_ROWGRP) == 0) __builtin_amdgcn_sched_barrier(0);     // bound the interleave (registers)
+      if (rb.on(r)) {
+        f32x4 v[NCH];
+        rb.get(r, v);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float q = fast_rcp(s.g * v[c][t] + vb[c][t]);
+            a1[c][t] += q;
+            a2[c][t] += q * q;
+          }
+      }
+    }
+    const float q = fast_rcp(s.g * rb.xr + vbx) * rb.xmask(fc);
+    a1x = wave_sum(q);
+    a2x = wave_sum(q * q);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a2[c][t] *= s.x2[c][t];
+    fc.store_row(a.A1 + (size_t)n * a.Fs, a1, a1x);
+    fc.store_row(a.P + (size_t)n * a.Fs, a2, a2x * s.x2x);
+  };
+  auto slots = [&](int n) { return n < n_end ? RBt::load_slots(fc, a.src + n, 0, a.R) : 0; };
+  RBt rbA, rbB;
+  FS sA, sB;
+  int sl1 = slots(n_beg + 1);
+  request(n_beg, rbA, sA, slots(n_beg));
+  for (int n = n_beg; n < n_end; n += 2) {
+    int sl2 = 0, sl3 = 0;
+    if (n + 1 < n_end) { request(n + 1, rbB, sB, sl1); sl2 = slots(n + 2); }
+    compute(n, rbA, sA);
+    if (n + 1 < n_end) {
+      if (n + 2 < n_end) { request(n + 2, rbA, sA, sl2); sl3 = slots(n + 3); }
+      compute(n + 1, rbB, sB);
+    }
+    sl1 = sl3;
+  }
+}
+
+template <int NCH, int KP, typename ST, int RT>
+__global__ __launch_bounds__(256, 2) void hg_stream2_kernel(const StreamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  FrameCtx<NCH, KP, ST> fc(a, wlds + (KP <= 8 ? (size_t)(threadIdx.x >> 6) * a.Fs * KP : 0));
+  fc.stage_block_w();
+  using RBt = RowBatch<NCH, ST, 1, RT>;
+  using FS = FrameSmall<NCH, KP>;
+  int n_beg, n_end;
+  wave_frames(a.NT, n_beg, n_end);
+  if (n_beg >= n_end) return;
+  __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.VsS), 0, (int)((unsigned)a.NT * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST)), 0x00020000);
+  // slots are requested TWO frames ahead, rows and operands one frame ahead: the row addresses depend on the slots,
+  // and a wait for the slots placed between two frames' row loads would expose a full memory round trip per frame
+  auto request = [&](int n, RBt& rb, FS& s, int sl) {
+    s.utt = a.frame_utt[n];
+    s.g = a.g[n];
+    if (!a.gains_only) {
+#pragma unroll
+      for (int k = 0; k < KP; k += 4) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
+        const f32x4 nv = *reinterpret_cast<const f32x4*>(a.normW + (size_t)s.utt * KP + k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s.h[k + t] = hv[t] * nv[t];      // H carries the pending column norms of W
+      }
+    }
+    fc.load_x2(n, s.x2, s.x2x);
+    rb.load_rows_buf(fc, vrs, (unsigned)n * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST), sl, a.R);
+  };
+  auto compute = [&](int n, RBt& rb, const FS& s) {
+    const int utt = s.utt;
+    const float gn = s.g;
+    f32x4 vb[NCH];
+    float vbx;
+    if (a.gains_only) {
+      fc.ext_var(n, vb, vbx);
+    } else {
+      // ---- H update (mcem.py:118-121): W already updated and normalised
+      fc.set_utt(utt);
+      fc.noise_var(utt, s.h, vb, vbx);
+      f32x4 a1[NCH], a2[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) a1[c] = a2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < RBt::RB; ++r) {
+        if (RT > 0 && (r % VN_ROWGRP) == 0) __builtin_amdgcn_sched_barrier(0);
+        if (rb.on(r)) {
+          f32x4 v[NCH];
+          rb.get(r, v);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
+              a1[c][t] += q;
+              a2[c][t] += q * q;
+            }
+        }
+      }
+      const float qx = fast_rcp(gn * rb.xr + vbx) * rb.xmask(fc);
+      float a1x = wave_sum(qx), a2x = wave_sum(qx * qx);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          a2[c][t] = fc.cv[c] ? a2[c][t] * s.x2[c][t] : 0.f;
+          a1[c][t] = fc.cv[c] ? a1[c][t] : 0.f;
+        }
+      const bool lead = fc.lane == 0 && fc.has_x;
+      a2x = lead ? a2x * s.x2x : 0.f;
+      a1x = lead ? a1x : 0.f;
+      float hn[KP];
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        float nu, de;
+        fc.w_dot(utt, k, a2, a1, a2x, a1x, nu, de);
+        nu = wave_sum(nu);
+        de = wave_sum(de);
+        hn[k] = k < a.K ? s.h[k] * __builtin_amdgcn_sqrtf(nu * fast_rcp(de)) : 0.f;        // mcem.py:121
+      }
+      if (fc.lane == 0) {
+#pragma unroll
+        for (int k = 0; k < KP; k += 4)
+          *reinterpret_cast<f32x4*>(a.Ht + (size_t)n * KP + k) = f32x4{hn[k], hn[k + 1], hn[k + 2], hn[k + 3]};
+      }
+      fc.noise_var(utt, hn, vb, vbx);                                                      // mcem.py:124-125
+    }
+    // ---- g update (mcem.py:138-142 / :564-568)
+    float nu = 0.f, de = 0.f;
+    rb.repack();
+    {
+      f32x4 ng[NCH], dg[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) ng[c] = dg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < RBt::RB; ++r) {
+        if (RT > 0 && (r % VN_ROWGRP) == 0) __builtin_amdgcn_sched_barrier(0);
+        if (rb.on(r)) {
+          f32x4 v[NCH];
+          rb.get(r, v);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
+              const float vq = v[c][t] * q;
+              dg[c][t] += vq;                 // sum_r Vs / Vx
+              ng[c][t] += vq * q;             // sum_r Vs / Vx^2
+            }
+        }
+      }
+      const float q = fast_rcp(gn * rb.xr + vbx), vq = rb.xr * q * rb.xmask(fc);
+      const float dgx = wave_sum(vq), ngx = wave_sum(vq * q);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (fc.cv[c]) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { nu += s.x2[c][t] * ng[c][t]; de += dg[c][t]; }
+        }
+      if (fc.lane == 0 && fc.has_x) { nu += s.x2x * ngx; de += dgx; }
+      nu = wave_sum(nu);
+      de = wave_sum(de);
+    }
+    const float gnew = gn * __builtin_amdgcn_sqrtf(nu * fast_rcp(de));                     // mcem.py:142
+    if (fc.lane == 0) a.g[n] = gnew;
+    // ---- cost (mcem.py:70) with the refreshed variances (:151-152); samples two at a time
+    rb.repack();
+    f32x4 cl[NCH], cx[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) cl[c] = cx[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < RBt::RB; r += 2) {
+      if (rb.on(r + 1)) {
+        f32x4 v0[NCH], v1[NCH];
+        rb.get(r, v0);
+        rb.get(r + 1, v1);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float x0 = gnew * v0[c][t] + vb[c][t], x1 = gnew * v1[c][t] + vb[c][t];
+            const float pp = x0 * x1;
+            cl[c][t] += fast_log2(pp);
+            cx[c][t] += (x0 + x1) * fast_rcp(pp);
+          }
+      } else if (rb.on(r)) {
+        f32x4 v0[NCH];
+        rb.get(r, v0);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float x0 = gnew * v0[c][t] + vb[c][t];
+            cl[c][t] += fast_log2(x0);
+            cx[c][t] += fast_rcp(x0);
+          }
+      }
+    }
+    const float xm = rb.xmask(fc), x0 = gnew * rb.xr + vbx;
+    const float clx = wave_sum(fast_log2(x0) * xm), cxx = wave_sum(fast_rcp(x0) * xm);
+    float cs = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (fc.cv[c]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cs += cl[c][t] * LN2_F + s.x2[c][t] * cx[c][t];
+      }
+    if (fc.lane == 0 && fc.has_x) cs += clx * LN2_F + s.x2x * cxx;
+    const double cd = sum_rows4_d((double)sum_row16(cs));     // rows in fp32 (DPP), then fp64 across the 4 rows
+    if (fc.lane == 0) a.cost_frames[n] = cd;
+  };
+  auto slots = [&](int n) { return n < n_end ? RBt::load_slots(fc, a.src + n, 0, a.R) : 0; };
+  RBt rbA, rbB;
+  FS sA, sB;
+  int sl1 = slots(n_beg + 1);
+  request(n_beg, rbA, sA, slots(n_beg));
+  for (int n = n_beg; n < n_end; n += 2) {
+    int sl2 = 0, sl3 = 0;
+    if (n + 1 < n_end) { request(n + 1, rbB, sB, sl1); sl2 = slots(n + 2); }
+    compute(n, rbA, sA);
+    if (n + 1 < n_end) {
+      if (n + 2 < n_end) { request(n + 2, rbA, sA, sl2); sl3 = slots(n + 3); }
+      compute(n + 1, rbB, sB);
+    }
+    sl1 = sl3;
+  }
+}
+
 StreamArgs base_args(const vaenmf_plan* p) {
   StreamArgs a = {};
   a.VsS = p->VsS; a.src = p->src; a.frame_utt = p->d_frame_utt; a.Vb = p->Vb_ext;
   a.store_f32 = p->cfg.precision == VAENMF_PREC_BF16X3;
+  a.n_sms = p->n_sms;
   a.NT = p->NT; a.R = p->store_R; a.Rs = p->store_Rs; a.F = p->cfg.F; a.Fm = p->Fm; a.Fs = p->Fs; a.K = p->cfg.K;
   return a;
 }
@@ -619,6 +955,25 @@ int launch_st(StreamArgs a, int grid, hipStream_t st) {
   const void* fn = KIND == SK_WSTATS ? (const void*)wstats_stream_kernel<NCH, KP, ST>
                    : (KIND == SK_HG ? (const void*)hg_stream_kernel<NCH, KP, ST> : (const void*)wf_stream_kernel<NCH, KP, ST>);
   if (int e = vn_ensure_dyn_lds(fn, 80 * 1024)) return e;
+  constexpr bool PIPE_OK = NCH == 1 && KP <= 8;
+  if (PIPE_OK && VN_STREAM2 && (KIND == SK_WSTATS || (KIND == SK_HG && VN_STREAM2 > 1)) && a.R <= RowBatch<NCH, ST>::RB) {
+    // frame-pipelined forms: two resident wavefronts per SIMD, one resident set per launch
+    int g2 = a.n_sms * 2;
+    if (g2 * 4 > a.NT) g2 = (a.NT + 3) / 4;
+    constexpr int N1 = PIPE_OK ? NCH : 1, K1 = PIPE_OK ? KP : 8;
+#define VN_GO2(RT)                                                                                                                 \
+    do {                                                                                                                               \
+      const void* fn2 = KIND == SK_WSTATS ? (const void*)wstats_stream2_kernel<N1, K1, ST, RT> : (const void*)hg_stream2_kernel<N1, K1, ST, RT>; \
+      if (int e = vn_ensure_dyn_lds(fn2, 80 * 1024)) return e;                                                                         \
+      if (KIND == SK_WSTATS) hipLaunchKernelGGL((wstats_stream2_kernel<N1, K1, ST, RT>), dim3(g2), dim3(256), lds, st, a);             \
+      else hipLaunchKernelGGL((hg_stream2_kernel<N1, K1, ST, RT>), dim3(g2), dim3(256), lds, st, a);                                    \
+    } while (0)
+    // (exact-row-count instantiations, RT = 30 / 10, were measured: without the per-row branches the compiler
+    // interleaves every row and spills -- W-statistics 0.29 vs 0.155 ms, H/g 0.79 vs 0.29 ms -- so only RT = 0 ships)
+    VN_GO2(0);
+#undef VN_GO2
+    return 0;
+  }
   if (KIND == SK_WSTATS) hipLaunchKernelGGL((wstats_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
   else if (KIND == SK_HG) hipLaunchKernelGGL((hg_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
   else hipLaunchKernelGGL((wf_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
