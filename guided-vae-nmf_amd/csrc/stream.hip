@@ -231,9 +231,11 @@ struct RowBatch {
   __device__ __forceinline__ void load_rows_buf(const FC& fc, __amdgpu_buffer_rsrc_t rs, unsigned frame_off, int sl, int R) {
     nr = RT > 0 ? RT : (R < RB ? R : RB);
     const unsigned rowb = (unsigned)fc.a.Fs * (unsigned)sizeof(ST);
+    // (raw bits: the conversion would wait for this load before the row loads below are even issued; finish_x()
+    // converts at the first use, a frame later)
     if (fc.has_x) {
       const unsigned o = frame_off + (unsigned)sl * rowb + (unsigned)(fc.a.F - 1) * (unsigned)sizeof(ST);
-      if constexpr (sizeof(ST) == 2) xr = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, o, 0, 0) << 16);
+      if constexpr (sizeof(ST) == 2) xr = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, o, 0, 0));
       else xr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0));
     } else xr = 0.f;
 #pragma unroll
@@ -247,6 +249,9 @@ struct RowBatch {
           else raw[r][c] = __builtin_bit_cast(raw_t, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
         }
       }
+  }
+  __device__ __forceinline__ void finish_x() {        // after load_rows_buf: extra-bin bits -> float
+    if constexpr (sizeof(ST) == 2) xr = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, xr) << 16);
   }
   // Between two passes over the same batch: without this the compiler keeps the UNPACKED floats of the first pass
   // alive for the next one (common-subexpression elimination of the bf16 -> float conversions: 120 registers).
@@ -669,8 +674,15 @@ template <int NCH, int KP>
 struct FrameSmall {            // the per-frame operands besides the rows, requested one frame ahead like the rows
   f32x4 x2[NCH];
   float x2x, g;
-  float h[KP];
+  float h[KP];               // H[:, n] (hg: requested as loaded; times the pending column norms in finish())
+  float nrm[KP];
   int utt;
+  __device__ __forceinline__ void finish(bool with_norms) {
+    if (with_norms) {
+#pragma unroll
+      for (int k = 0; k < KP; ++k) h[k] *= nrm[k];
+    }
+  }
 };
 
 template <int NCH, int KP, typename ST, int RT>
@@ -698,7 +710,8 @@ __global__ __launch_bounds__(256, 2) void wstats_stream2_kernel(const StreamArgs
     fc.load_x2(n, s.x2, s.x2x);
     rb.load_rows_buf(fc, vrs, (unsigned)n * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST), sl, a.R);
   };
-  auto compute = [&](int n, const RBt& rb, const FS& s) {
+  auto compute = [&](int n, RBt& rb, const FS& s) {
+    rb.finish_x();
     fc.set_utt(s.utt);
     f32x4 vb[NCH], a1[NCH], a2[NCH];
     float vbx, a1x = 0.f, a2x = 0.f;
@@ -770,13 +783,15 @@ __global__ __launch_bounds__(256, 2) void hg_stream2_kernel(const StreamArgs a) 
         const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
         const f32x4 nv = *reinterpret_cast<const f32x4*>(a.normW + (size_t)s.utt * KP + k);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) s.h[k + t] = hv[t] * nv[t];      // H carries the pending column norms of W
+        for (int t = 0; t < 4; ++t) { s.h[k + t] = hv[t]; s.nrm[k + t] = nv[t]; }      // (multiplied in compute: no wait here)
       }
     }
     fc.load_x2(n, s.x2, s.x2x);
     rb.load_rows_buf(fc, vrs, (unsigned)n * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST), sl, a.R);
   };
-  auto compute = [&](int n, RBt& rb, const FS& s) {
+  auto compute = [&](int n, RBt& rb, FS& s) {
+    rb.finish_x();
+    s.finish(!a.gains_only);                    // H carries the pending column norms of W
     const int utt = s.utt;
     const float gn = s.g;
     f32x4 vb[NCH];
