@@ -120,15 +120,18 @@ __device__ __forceinline__ f32x4 mma(const bf16x8 whi, const bf16x8 wlo, const b
 // MAXT : compile-time bound of the bin tiles; EXACT: NT3 == MAXT (no per-tile checks)
 // LOL  : the lo fragments of W3 are in LDS too (bf16x3 mode, small F); otherwise they stream from L2
 // HIALL: every hi fragment of W3 is in LDS
+// GT   : the hi fragments of the FIRST GT bin tiles stay in global memory (F = 513: W3 does not fit the LDS whole); a
+//        wavefront requests them at the top of every evaluation, two layers before their use, and before any store of
+//        that evaluation (vmcnt counts in order); LDS holds tiles GT..NT3-1
 // M2   : per-frame layer-1 bias B1 = b1 + W1[:, L:] y_n (kept in registers), else b1 from LDS
-template <int MAXT, bool EXACT, bool SPLIT, bool STORE, int NWAVES, bool LOL, bool HIALL, bool M2>
+template <int MAXT, bool EXACT, bool SPLIT, bool STORE, int NWAVES, bool LOL, bool HIALL, bool M2, int GT>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const WcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = WcLds<SPLIT>;
   constexpr int PARTS = L::PARTS;
   using store_t = typename std::conditional<SPLIT, float, __bf16>::type;
   const int NT3 = EXACT ? MAXT : a.NT3;
-  const int n_hi = HIALL ? NT3 : a.n_hi_lds;
+  const int n_hi = HIALL ? NT3 - GT : a.n_hi_lds;
 
   // ---- workgroup prologue: weights and biases into LDS (the only barrier of the kernel)
   {
@@ -142,8 +145,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
     };
     stage(smem + L::W1, a.w1f, NTH);
     stage(smem + L::W2, a.w2f, NTH * NK);
-    for (int e = threadIdx.x; e < n_hi * NK * 64; e += nthr) {      // hi blocks of W3
-      const int chunk = e & 63, b = e >> 6;
+    for (int e = threadIdx.x; e < n_hi * NK * 64; e += nthr) {      // hi blocks of W3 (tiles GT..)
+      const int chunk = e & 63, b = (e >> 6) + GT * NK;
       *reinterpret_cast<f32x4*>(smem + L::W3 + (size_t)e * 16) =
           *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.w3f) + ((size_t)(b * 2) * 64 + chunk) * 16);
     }
@@ -318,6 +321,13 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
           VN_SB;
         }
       };
+      bf16x8 gfr[GT > 0 ? GT : 1][NK];                 // hi fragments of the bin tiles that live in global memory (L2)
+      if (GT > 0) {
+#pragma unroll
+        for (int t = 0; t < GT; ++t)
+#pragma unroll
+          for (int s = 0; s < NK; ++s) gfr[t][s] = *reinterpret_cast<const bf16x8*>(w3g + (size_t)((t * NK + s) * 2) * 1024 + l16);
+      }
       // ---- layer 1: input = the latents of this lane's frame (one k-step)
       {
         bh[0][0] = pk2(zz[0], zz[1]); bh[0][1] = pk2(zz[2], zz[3]); bh[0][2] = pk2(zz[4], zz[5]); bh[0][3] = pk2(zz[6], zz[7]);
@@ -355,7 +365,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
       unsigned pk_even0 = 0, pk_even1 = 0;
       run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, MAXT>{},
                 [&](int t, int s, bf16x8& hi, bf16x8& lo) {
-                  if (HIALL || t < n_hi) hi = *reinterpret_cast<const bf16x8*>(smem + L::W3 + (t * NK + s) * 1024 + l16);
+                  if (GT > 0 && t < GT) hi = gfr[t < GT ? t : 0][s];
+                  else if (HIALL || t - GT < n_hi) hi = *reinterpret_cast<const bf16x8*>(smem + L::W3 + ((t - GT) * NK + s) * 1024 + l16);
                   else hi = *reinterpret_cast<const bf16x8*>(w3g + (size_t)((t * NK + s) * 2) * 1024 + l16);
                   if (!SPLIT) lo = hi;
                   else if (LOL) lo = *reinterpret_cast<const bf16x8*>(w3lo_lds + (t * NK + s) * 1024 + l16);
@@ -505,36 +516,38 @@ namespace {
 
 constexpr int WC_LDS_LIMIT = 160 * 1024;
 
-template <int MAXT, bool EXACT, bool SPLIT, bool STORE, int NWAVES, bool LOL, bool HIALL, bool M2>
+template <int MAXT, bool EXACT, bool SPLIT, bool STORE, int NWAVES, bool LOL, bool HIALL, bool M2, int GT = 0>
 int wc_launch(const WcArgs& a, int grid, size_t lds, hipStream_t st) {
-  auto* fn = wchain_kernel<MAXT, EXACT, SPLIT, STORE, NWAVES, LOL, HIALL, M2>;
+  auto* fn = wchain_kernel<MAXT, EXACT, SPLIT, STORE, NWAVES, LOL, HIALL, M2, GT>;
   if (int e = vn_ensure_dyn_lds((const void*)fn, WC_LDS_LIMIT)) return e;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(NWAVES * 64), lds, st, a);
   return 0;
 }
 // M1 runs NW1 wavefronts per workgroup, M2 (32 more registers: the per-frame layer-1 bias) always 4
-template <int MAXT, bool EXACT, bool SPLIT, int NW1, bool LOL>
+template <int MAXT, bool EXACT, bool SPLIT, int NW1, bool LOL, int GT = 0>
 int wc_launch_s(const WcArgs& a, int nwt, int n_sms, size_t lds, hipStream_t st) {
   const int nw = a.B1 ? 4 : NW1;
   int grid = (nwt + nw - 1) / nw;
   if (grid > n_sms) grid = n_sms;                       // one workgroup per CU (LDS), wave tiles in a grid-stride loop
   if (a.B1) {
 #if !defined(VN_DEV_FAST) || defined(VN_DEV_M2)
-    return a.VsS ? wc_launch<MAXT, EXACT, SPLIT, true, 4, LOL, true, true>(a, grid, lds, st)
-                 : wc_launch<MAXT, EXACT, SPLIT, false, 4, LOL, true, true>(a, grid, lds, st);
+    return a.VsS ? wc_launch<MAXT, EXACT, SPLIT, true, 4, LOL, true, true, GT>(a, grid, lds, st)
+                 : wc_launch<MAXT, EXACT, SPLIT, false, 4, LOL, true, true, GT>(a, grid, lds, st);
 #else
     return -1;
 #endif
   }
-  return a.VsS ? wc_launch<MAXT, EXACT, SPLIT, true, NW1, LOL, true, false>(a, grid, lds, st)
-               : wc_launch<MAXT, EXACT, SPLIT, false, NW1, LOL, true, false>(a, grid, lds, st);
+  return a.VsS ? wc_launch<MAXT, EXACT, SPLIT, true, NW1, LOL, true, false, GT>(a, grid, lds, st)
+               : wc_launch<MAXT, EXACT, SPLIT, false, NW1, LOL, true, false, GT>(a, grid, lds, st);
 }
 
 }  // namespace
 
 // Shapes the wave-private chain covers (the rest runs engine.hip's team kernel): every W3 hi fragment in LDS
 bool vn_wchain_supported(const vaenmf_plan* p) {
-  if (p->NT3c > 17) return false;
+  // up to 17 bin tiles (F <= 272) in both precision modes; F = 513..528 (33 tiles, the reference scripts' 1024-pt STFT)
+  // in bf16 mode with four tiles' fragments streamed from L2
+  if (p->NT3c > 17 && !(p->NT3c == 33 && p->cfg.precision == VAENMF_PREC_BF16)) return false;
   const char* e = getenv("VAENMF_TEAM_CHAIN");          // dev / test override: force the team kernel of engine.hip
   return !(e && e[0] == '1');
 }
@@ -553,14 +566,16 @@ int vn_launch_wchain(vaenmf_plan* p, const VnChainCall& cc, hipStream_t st) {
   a.rng_mode = cc.rng_mode; a.update_Z = cc.update_Z; a.call = cc.call; a.sd = cc.sd;
   a.n_hi_lds = p->NT3c;
   const size_t fixed = split ? WcLds<true>::fixed_bytes : WcLds<false>::fixed_bytes;
-  const size_t w3hi = (size_t)p->NT3c * NK * 1024;
+  constexpr int GT33 = 4;                                // F = 513: bin tiles whose fragments stay in global memory
+  const size_t w3hi = (size_t)(p->NT3c == 33 ? p->NT3c - GT33 : p->NT3c) * NK * 1024;
   const bool lol = split && p->NT3c <= 5;              // bf16x3: the lo fragments of W3 fit in LDS up to 5 tiles (F <= 80), else they stream from L2
   const size_t lds = fixed + w3hi * (lol ? 2 : 1);
   VN_REQUIRE(lds <= (size_t)WC_LDS_LIMIT, "wave chain: %zu bytes of LDS needed", lds);
   // wavefronts per workgroup: 8 (two per SIMD, 256 registers each) in bf16 mode, 4 (512 registers) in bf16x3 mode
   constexpr int NW_BF16 = VN_WC_WAVES_BF16, NW_X3 = 4;
   int rc = -1;
-  if (p->NT3c == 17)     rc = split ? wc_launch_s<17, true, true, NW_X3, false>(a, p->n_wtiles, p->n_sms, lds, st) : wc_launch_s<17, true, false, NW_BF16, false>(a, p->n_wtiles, p->n_sms, lds, st);
+  if (p->NT3c == 33)     rc = wc_launch_s<33, true, false, 4, false, GT33>(a, p->n_wtiles, p->n_sms, lds, st);
+  else if (p->NT3c == 17) rc = split ? wc_launch_s<17, true, true, NW_X3, false>(a, p->n_wtiles, p->n_sms, lds, st) : wc_launch_s<17, true, false, NW_BF16, false>(a, p->n_wtiles, p->n_sms, lds, st);
   else if (p->NT3c == 5) rc = split ? wc_launch_s<5, true, true, NW_X3, true>(a, p->n_wtiles, p->n_sms, lds, st)   : wc_launch_s<5, true, false, NW_BF16, false>(a, p->n_wtiles, p->n_sms, lds, st);
 #ifndef VN_DEV_FAST
   else if (p->NT3c < 5)  rc = split ? wc_launch_s<5, false, true, NW_X3, true>(a, p->n_wtiles, p->n_sms, lds, st)  : wc_launch_s<5, false, false, NW_BF16, false>(a, p->n_wtiles, p->n_sms, lds, st);
