@@ -21,6 +21,9 @@
 #ifndef VN_WS_WAVES
 #define VN_WS_WAVES 4
 #endif
+#ifndef VN_HG_REPACK
+#define VN_HG_REPACK 1
+#endif
 #ifndef VN_ROWGRP
 #define VN_ROWGRP 6     // rows whose arithmetic the scheduler may interleave in the exact-count stream kernels
 #endif
@@ -486,6 +489,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
     }
     // ---- g update (mcem.py:138-142 / :564-568)
     float nu = 0.f, de = 0.f;
+    if (one && VN_HG_REPACK) rb.repack();      // (no unpacked floats carried from pass to pass: see RowBatch::repack)
     {
       f32x4 ng[NCH], dg[NCH];
       float ngx = 0.f, dgx = 0.f;
@@ -524,6 +528,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
     }
     const float gnew = gn * __builtin_amdgcn_sqrtf(nu * fast_rcp(de));                     // mcem.py:142
     if (fc.lane == 0) a.g[n] = gnew;
+    if (one && VN_HG_REPACK) rb.repack();
     // ---- cost (mcem.py:70) with the refreshed variances (:151-152); samples two at a time:
     // log Vx0 + log Vx1 = log(Vx0 Vx1), 1/Vx0 + 1/Vx1 = (Vx0 + Vx1)/(Vx0 Vx1)
     f32x4 cl[NCH], cx[NCH];

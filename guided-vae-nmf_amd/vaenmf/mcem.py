@@ -201,16 +201,15 @@ class MCEM_M2(_MCEM):
         self._init(X, y, vae, nmf_rank, eps, device)
 
 
-class MCEM_M2_noNMF(_MCEM):
-    """Reference surface of MCEM_M2_noNMF (mcem.py:606-760): constructor-style, the noise variance Vb is
-    given and fixed, only the gains are updated.  X complex (N,F), Vb (N,F), g (N,), Z (N,L), y (N,Dy)."""
+class EM_noNMF(_MCEM):
+    """Reference surface of EM_noNMF (mcem.py:493-604): "meant to be an abstract class that should not be instantiated
+    but only inherited" -- constructor (X, Vb, g, vae, niter, device), fixed noise variance Vb, gains-only M-step
+    (:543-578), run() (:580-604).  The sampler comes from the subclass (MCEM_M2_noNMF)."""
     model = "M2"
 
-    def __init__(self, X, Vb, g, Z, y, vae, niter, device, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25,
+    def __init__(self, X, Vb, g, vae, niter=100, device="cpu", nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25,
                  burnin_WF=75, var_RW=0.01, rng="replay", precision="bf16x3"):
         super().__init__(niter, nsamples_E_step, burnin_E_step, nsamples_WF, burnin_WF, var_RW, rng=rng, precision=precision)
-        if type(vae).__name__ == "RVAE":
-            raise NameError("MCEM algorithm only valid for FFNN VAE")          # mcem.py:614-615
         dev = torch.device(device if device not in (None, "cpu") else "cuda:0")
         N, F = X.shape
         sd = _state(vae)
@@ -225,18 +224,27 @@ class MCEM_M2_noNMF(_MCEM):
         vb = torch.zeros(N, eng.Fs, dtype=torch.float32)
         vb[:, :F] = torch.as_tensor(np.asarray(Vb), dtype=torch.float32)
         eng.set_noise_psd(vb)                                                  # mcem.py:507
-        eng.g.copy_(torch.as_tensor(g, dtype=torch.float32).reshape(N))
-        eng.Z.copy_(torch.as_tensor(Z, dtype=torch.float32).reshape(N, LAT))   # mcem.py:617
-        yy = torch.as_tensor(y, dtype=torch.float32).to(dev).reshape(N, -1).contiguous()
-        eng.set_labels(yy)
-        self.y = torch.t(yy)
+        eng.g.copy_(torch.as_tensor(g, dtype=torch.float32).reshape(N))        # mcem.py:508
         self._call = 0
 
     @property
     def Vb(self):
         return self._eng._Vb_ext[:, :self._F].T
 
-    def run(self):
-        if self.rng == "device":
-            raise NotImplementedError("the fused driver runs the NMF model; use rng='replay' stepping for noNMF")
-        return super().run()
+
+class MCEM_M2_noNMF(EM_noNMF):
+    """Reference surface of MCEM_M2_noNMF (mcem.py:606-760): constructor-style, the noise variance Vb is given and
+    fixed, only the gains are updated.  X complex (N,F), Vb (N,F), g (N,), Z (N,L), y (N,Dy).  rng="device" runs the
+    fused driver (vaenmf_em_run serves the fixed-noise model too: the chain reads the given Vb, the M-step is gains-only)."""
+
+    def __init__(self, X, Vb, g, Z, y, vae, niter, device, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25,
+                 burnin_WF=75, var_RW=0.01, rng="replay", precision="bf16x3"):
+        if type(vae).__name__ == "RVAE":
+            raise NameError("MCEM algorithm only valid for FFNN VAE")          # mcem.py:614-615
+        super().__init__(X, Vb, g, vae, niter, device, nsamples_E_step, burnin_E_step, nsamples_WF, burnin_WF, var_RW,
+                         rng=rng, precision=precision)
+        eng, N = self._eng, self._N
+        eng.Z.copy_(torch.as_tensor(Z, dtype=torch.float32).reshape(N, LAT))   # mcem.py:617
+        yy = torch.as_tensor(y, dtype=torch.float32).to(self.device).reshape(N, -1).contiguous()
+        eng.set_labels(yy)
+        self.y = torch.t(yy)                                                   # mcem.py:618

@@ -497,6 +497,98 @@ def test_file_driver_ragged_batch(tmp_path):
         assert len(wavio.read(sa)[0]) == lens[name] and np.all(np.isfinite(wavio.read(sa)[0]))
 
 
+def _processed_subset_tree(tmp_path):
+    """The reference's committed processed utterances si_et_05/440/440c020{a,b,c}_{s,n,x}.wav, cropped to 1.25 s
+    (tests/golden/processed_subset.npz: int16 samples, data only), written back as the tree the drivers read."""
+    from vaenmf import wavio
+    z = np.load(GOLDEN + "/processed_subset.npz")
+    root = str(tmp_path) + "/"
+    raw, proc = root + "raw/", root + "processed/"
+    for u, rel in zip("abc", z["rel"]):
+        for base in (raw, proc):
+            os.makedirs(os.path.dirname(base + str(rel)), exist_ok=True)
+        wavio.write(raw + str(rel), z[u + "_x"] / 32768.0, 16000)
+        for k in "snx":
+            wavio.write(proc + os.path.splitext(str(rel))[0] + "_%s.wav" % k, z["%s_%s" % (u, k)] / 32768.0, 16000)
+    return z, root, raw, proc
+
+
+def test_driver_and_metrics_on_reference_utterances(tmp_path):
+    """Rows f1 / f2 on the reference's OWN files: evaluate_M1-style driver -> run_metrics_M1-style harness on a cropped
+    subset of data/subset/processed, with the input SNRs of its si_et_05_snr_db.p (tests/golden/snr_db.npz).
+    Checks: (1) the harness' SI-SDR / SI-SIR / SI-SAR equal the oracle's energy_ratios on the very files the driver
+    wrote (1e-6 dB); the per-SNR table groups like metrics.py:93-104; (2) the 'oracle' and 'timo' label sources of
+    evaluate_M2_ibm.py:132-141 dump exactly the labels the oracle computes from the same wavs; (3) one utterance
+    through the drop-in MCEM_M1 with REPLAYED noise against the oracle run on the same draws: same cost trajectory,
+    SI-SDR of the enhanced signal within 0.02 dB."""
+    need_gpu()
+    import vaenmf
+    from vaenmf import wavio, run_metrics
+    from vaenmf.driver import evaluate, speech_list
+    from vaenmf.pipeline import Reconstructor
+    z, root, raw, proc = _processed_subset_tree(tmp_path)
+    files = speech_list(raw, "test")
+    assert files == [str(r) for r in z["rel"]]
+    snr = np.load(GOLDEN + "/snr_db.npz")["processed__CSR-1-WSJ-0__si_et_05_snr_db"]
+    F, K = 513, 10
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=0)
+    rec = Reconstructor(params, F, K, niter=5, fs=16000, wlen_sec=64e-3, precision="bf16x3", max_frames=400, max_utts=4)
+    out = root + "models/M1/"
+    evaluate(rec, files, proc, out, batch_size=8)
+    all_metrics, st = run_metrics.main(files, proc, out, snr)
+    for fp, m in zip(files, all_metrics):
+        stem = os.path.splitext(fp)[0]
+        ref = orc.energy_ratios(wavio.read(out + stem + "_s_est.wav")[0], wavio.read(proc + stem + "_s.wav")[0], wavio.read(proc + stem + "_n.wav")[0])
+        assert np.max(np.abs(np.asarray(m) - np.asarray(ref))) < 1e-6
+    assert st[0, 0, 0] == 3 and st[1, 0, 0] == 1 and st[2, 0, 0] == 2          # all, SNR -5 (1 utterance), SNR 0 (2)
+    assert abs(st[2, 0, 1] - (all_metrics[1][0] + all_metrics[2][0])) < 1e-9
+    # (2) label sources
+    p2 = orc.xavier_normal_params([F, 32, [128, 128]], seed=1, y_dim=F)
+    rec2 = Reconstructor(p2, F, K, niter=2, model="M2", fs=16000, wlen_sec=64e-3, precision="bf16", max_frames=400, max_utts=4)
+    for src in ("oracle", "timo"):
+        evaluate(rec2, files, proc, root + "models/M2_%s/" % src, batch_size=8, label_source=src, label_type="ibm", quantile_fraction=0.999, quantile_weight=0.999)
+        for fp in files:
+            stem = os.path.splitext(fp)[0]
+            hard = torch.load(root + "models/M2_%s/" % src + stem + "_ibm_hard_est.pt", weights_only=True).numpy()
+            if src == "oracle":
+                S = orc.stft(wavio.read(proc + stem + "_s.wav")[0], fs=16000, wlen_sec=64e-3)
+                assert np.array_equal(hard, orc.clean_speech_IBM(S, 0.999, 0.999).T)
+            else:
+                X = orc.stft(wavio.read(proc + stem + "_x.wav")[0], fs=16000, wlen_sec=64e-3)
+                want = (orc.timo_mask_estimation(np.power(np.abs(X), 2)) > 0.5).T
+                assert np.mean(hard != want) < 1e-4          # (float64 recursion on |X|^2 of two STFTs that differ in the last bit)
+            assert np.all(np.isfinite(wavio.read(root + "models/M2_%s/" % src + stem + "_s_est.wav")[0]))
+    # (3) replayed noise on real audio, drop-in class against the oracle
+    stem = os.path.splitext(files[1])[0]
+    x, s, n = (wavio.read(proc + stem + "_%s.wav" % k)[0] for k in "xsn")
+    X = orc.stft(x, fs=16000, wlen_sec=64e-3).T
+    g = orc.NumpyRNG(5)
+    draws = []
+    class Rec:
+        def rand(self, *sh): a = g.rand(*sh); draws.append(a); return a
+        def randn(self, *sh): a = g.randn(*sh); draws.append(a); return a
+    o = orc.MCEMOracle("M1", 2)
+    o.init_parameters(X, params, K, 1e-8, Rec())
+    c_ref = o.run()
+    vae = vaenmf.VariationalAutoencoder([F, 32, [128, 128]])
+    vae.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+    m = vaenmf.MCEM_M1(2, rng="replay")
+    it = iter(draws)
+    _r, _n = torch.rand, torch.randn
+    torch.rand = lambda *a, **k: torch.tensor(next(it))
+    torch.randn = lambda *a, **k: torch.tensor(next(it))
+    try:
+        m.init_parameters(X=X, vae=vae, nmf_rank=K, eps=1e-8, device="cuda:0")
+        c = m.run()
+    finally:
+        torch.rand, torch.randn = _r, _n
+    assert np.max(np.abs(c - c_ref) / np.abs(c_ref)) < 1e-3
+    sd_ref = orc.energy_ratios(orc.istft(o.S_hat, fs=16000, wlen_sec=64e-3, max_len=len(x)).astype(np.float64), s, n)[0]
+    sd_gpu = orc.energy_ratios(orc.istft(m.S_hat, fs=16000, wlen_sec=64e-3, max_len=len(x)).astype(np.float64), s, n)[0]
+    print("replayed run on 440c020b: SI-SDR oracle %.4f dB, HIP %.4f dB" % (sd_ref, sd_gpu))
+    assert abs(sd_ref - sd_gpu) < 0.02
+
+
 def test_nonmf_variant_against_reference():
     """MCEM_M2_noNMF drop-in (mcem.py:606-760) with replayed noise against the reference's recorded run."""
     need_gpu()
@@ -520,6 +612,35 @@ def test_nonmf_variant_against_reference():
     assert rel_err(m.g.cpu().numpy(), z["g"]) < 2e-3
     assert np.max(np.abs(m.Z.cpu().numpy() - z["Z"])) < 1e-5
     assert nrm_err(m.S_hat, z["S_hat"]) < 2e-3 and nrm_err(m.N_hat, z["N_hat"]) < 2e-3
+
+
+def test_nonmf_fused_run_equals_stepwise():
+    """The fused driver (vaenmf_em_run, device generator) with a fixed noise PSD -- the *_noNMF model -- equals the
+    same run stepped through E_step / M_step / compute_WF with the device generator: bit for bit."""
+    need_gpu()
+    import vaenmf
+    z, params, draws, meta = load_case("m2_nonmf_f65")
+    nsE, biE, nsW, biW = meta["counts"]
+    vae = vaenmf.DeepGenerativeModel([meta["F"], meta["Dy"], meta["L"], [128, 128]], None)
+    vae.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+    assert issubclass(vaenmf.MCEM_M2_noNMF, vaenmf.EM_noNMF)
+    outs = []
+    for fused in (True, False):
+        m = vaenmf.MCEM_M2_noNMF(X=z["X"], Vb=z["Vb"], g=torch.tensor(z["g0"]), Z=torch.tensor(z["Z0"]), y=torch.tensor(z["y"]),
+                                 vae=vae, niter=3, device="cuda:0", nsamples_E_step=nsE, burnin_E_step=biE,
+                                 nsamples_WF=nsW, burnin_WF=biW, var_RW=0.01, rng="device")
+        if fused:
+            cost = m.run()
+        else:
+            cost = np.zeros(3)
+            for n in range(3):
+                m.E_step(); m.M_step(); cost[n] = m.compute_expected_neg_log_like()
+            m.compute_WF(sample=True)
+            F = meta["F"]
+            m.S_hat = np.ascontiguousarray(m._S_dev[:, :F].cpu().numpy()).view(np.complex64).reshape(m._N, F).T
+        outs.append((cost, m.S_hat, m.g.cpu().numpy()))
+    assert np.allclose(outs[0][0], outs[1][0], rtol=1e-12) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    assert np.all(np.isfinite(outs[0][0])) and outs[0][0][-1] < outs[0][0][0] * 1.5
 
 
 def test_label_front_ends_bit_exact():

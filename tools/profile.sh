@@ -1,12 +1,17 @@
 #!/bin/bash
-# dev aid (runs on the GPU box through gpurun): rocprofv3 kernel statistics and HBM-traffic counters of bench.py
+# dev aid (runs on the GPU box through gpurun): rocprofv3 kernel statistics and HBM-traffic / SQ counter passes of bench.py
+# usage: tools/profile.sh <precision> [round tag]     every rocprofv3 run is bounded (a hung pass must not eat the budget)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/prof_$1
-mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-mode --precision $1 > $OUT/bench_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 1 --warmup 0 --niter 10 --no-cpu-baseline --no-parity-mode --precision $1 > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 1 --warmup 0 --niter 10 --no-cpu-baseline --no-parity-mode --precision $1 > $OUT/bench_write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq -- python bench.py --steps 1 --warmup 0 --niter 10 --no-cpu-baseline --no-parity-mode --precision $1 > $OUT/bench_sq.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -- python bench.py --steps 1 --warmup 0 --niter 10 --no-cpu-baseline --no-parity-mode --precision $1 > $OUT/bench_grbm.log 2>&1
-ls -R $OUT | head -40
+OUT=gpurun_out/prof_${2:-r2}_$1
+rm -rf $OUT; mkdir -p $OUT
+B="--no-cpu-baseline --no-parity-mode --no-configs --precision $1"
+run() { name=$1; shift; timeout -k 10 240 rocprofv3 "$@" > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
+run bench_trace --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 2 --warmup 1 $B
+grep '^{' $OUT/bench_trace.log > $OUT/bench_trace.json
+run bench_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 1 --warmup 0 --niter 10 $B
+run bench_write --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 1 --warmup 0 --niter 10 $B
+run bench_sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq -- python bench.py --steps 1 --warmup 0 --niter 10 $B
+run bench_sq2 --pmc SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc_sq2 -- python bench.py --steps 1 --warmup 0 --niter 10 $B
+run bench_grbm --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -- python bench.py --steps 1 --warmup 0 --niter 10 $B
+ls $OUT
