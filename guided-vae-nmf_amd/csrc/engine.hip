@@ -1413,7 +1413,7 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
     const int Rs = nsamples + 1;
     const size_t esz = split ? sizeof(float) : sizeof(__bf16);
     const size_t need_v = (size_t)(p->NT + 1) * Rs * p->Fs * esz, need_s = (size_t)p->NT * Rs;   // + a spare block (idle lanes)
-    VN_REQUIRE(need_v < (1ull << 32), "sample store: %d frames x %d slots x %d bins exceeds the 32-bit byte offsets of "
+    VN_REQUIRE(need_v < 0xE0000000ull, "sample store: %d frames x %d slots x %d bins exceeds the 32-bit byte offsets of "
                "the chain kernel; bind a smaller batch or switch the store off", p->NT, Rs, p->Fs);
     VN_REQUIRE(need_v <= p->VsS_cap && need_s <= p->src_cap, "sample store too small for %d frames x %d samples: call "
                "vaenmf_sample_store(plan, max_samples) after vaenmf_bind_batch (no allocation happens in vaenmf_mh_chain)", p->NT, nsamples);
@@ -1457,7 +1457,7 @@ extern "C" int vaenmf_sample_store(vaenmf_plan* p, int32_t max_samples) {
   // sized for the bound batch (or, before a batch is bound, for the plan's frame capacity)
   const size_t frames = (size_t)(p->NT > 0 ? p->NT : p->cfg.max_frames) + 1, Rs = (size_t)max_samples + 1;
   size_t need_v = frames * Rs * p->Fs * esz, need_s = frames * Rs;
-  if (need_v >= (1ull << 32)) need_v = (1ull << 32) - 16;      // larger batches fall back to decoding (vaenmf_em_run)
+  if (need_v >= 0xE0000000ull) need_v = 0xE0000000ull - 16;    // larger batches fall back to decoding (vaenmf_em_run); offsets from 0xF0000000 mark idle lanes
   if (need_v > p->VsS_cap) {
     if (p->VsS) VN_CHECK_HIP(hipFree(p->VsS));
     p->VsS = nullptr; p->VsS_cap = 0;
@@ -1559,7 +1559,8 @@ extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* H
   // with the sample store on (vaenmf_sample_store), the chain leaves the samples' variances in HBM and the
   // M-step / Wiener filter stream them; otherwise they decode Zs again
   // (a batch too large for the store's 32-bit element offsets, or for the streaming kernels' bin range, decodes)
-  auto fits = [&](int ns) { return (size_t)(p->NT + 1) * (ns + 1) * p->Fs * 4 < (1ull << 32) && p->Fm <= 768; };
+  const size_t esz = p->cfg.precision == VAENMF_PREC_BF16X3 ? sizeof(float) : sizeof(__bf16);
+  auto fits = [&](int ns) { return (size_t)(p->NT + 1) * (ns + 1) * p->Fs * esz < 0xE0000000ull && p->Fm <= 768; };
   const bool want = p->store_on, stored = want && fits(nsE) && fits(nsWF);
   p->store_on = stored;
   p->last_m_step_path = stored ? 1 : 2;               // VAENMF_Q_MSTEP_PATH: the caller can see a fall back to decoding
