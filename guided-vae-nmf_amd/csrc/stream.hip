@@ -21,6 +21,9 @@
 #ifndef VN_WS_WAVES
 #define VN_WS_WAVES 4
 #endif
+#ifndef VN_HG_STAGGER
+#define VN_HG_STAGGER 0     // s_sleep(127) units (8128 cycles each) per hardware wave slot at the start of hg_stream
+#endif
 #ifndef VN_HG_REPACK
 #define VN_HG_REPACK 1
 #endif
@@ -88,7 +91,7 @@ struct FrameCtx {
     if (n_first < a.NT) {
       blk_utt = a.frame_utt[n_first];
       const f32x4* src = reinterpret_cast<const f32x4*>(a.W + (size_t)blk_utt * a.Fs * KP);
-      for (int e = threadIdx.x; e < a.Fs * KP / 4; e += blockDim.x) reinterpret_cast<f32x4*>(wl)[e] = src[e];
+      for (int e = threadIdx.x; e < a.Fs * KP / 4; e += blockDim.x) put_t(e, src[e]);
     }
     __syncthreads();
   }
@@ -99,17 +102,45 @@ struct FrameCtx {
     wutt = utt;
     __builtin_amdgcn_wave_barrier();                        // earlier reads of the previous utterance's rows
     const f32x4* src = reinterpret_cast<const f32x4*>(a.W + (size_t)utt * a.Fs * KP);
-    for (int e = lane; e < a.Fs * KP / 4; e += 64) reinterpret_cast<f32x4*>(wl)[e] = src[e];
+    for (int e = lane; e < a.Fs * KP / 4; e += 64) put_t(e, src[e]);
     __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the rows are in LDS (gfx9 encoding)
     __builtin_amdgcn_wave_barrier();
   }
+  // LDS copy of W[utt]: TRANSPOSED, wl[k][f].  A lane's bins are f0 + 4 lane .. +3: with the global layout [f][k]
+  // (row = 8 ranks = 32 B.. 128 B) the 64 lanes of a read hit one or two LDS banks (32-way conflicts: the LDS, not
+  // HBM or the VALU, bounded H/g: 45 conflicted reads per frame); rank-major, a lane reads its 4 bins of one rank
+  // with one ds_read_b128 and consecutive lanes are 16 B apart: conflict-free.
+  __device__ __forceinline__ void put_t(int e, const f32x4 v) {          // e-th float4 of W[utt] in global order [f][k]
+    const int f = e / (KP / 4), k = (e - f * (KP / 4)) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wl[(k + j) * a.Fs + f] = v[j];
+  }
   template <bool L>
-  __device__ __forceinline__ const float* w_row(int utt, int f) const {
-    return L ? wl + f * KP : a.W + ((size_t)utt * a.Fs + f) * KP;
+  __device__ __forceinline__ const float* w_row(int utt, int f) const {   // global layout only
+    return a.W + ((size_t)utt * a.Fs + f) * KP;
   }
   // Vb = sum_k W[f,k] h[k] for this lane's bins (+ the extra bin); set_utt(utt) first
   template <bool L>
   __device__ __forceinline__ void noise_var_(int utt, const float (&h)[KP], f32x4 (&vb)[NCH], float& vbx) const {
+    if (L) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (cv[c]) {
+#pragma unroll
+          for (int k = 0; k < KP; ++k) v += *reinterpret_cast<const f32x4*>(wl + k * a.Fs + f0[c]) * h[k];
+        }
+        vb[c] = cv[c] ? v : f32x4{1.f, 1.f, 1.f, 1.f};
+      }
+      vbx = 1.f;
+      if (has_x) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) v += wl[k * a.Fs + a.F - 1] * h[k];
+        vbx = v;
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       vb[c] = f32x4{1.f, 1.f, 1.f, 1.f};
@@ -148,15 +179,21 @@ struct FrameCtx {
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
       if (cv[c]) {
+        if (L) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + k * a.Fs + f0[c]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float w = w_row<L>(utt, f0[c] + t)[k];
-          nu += w * P[c][t];
-          de += w * A[c][t];
+          for (int t = 0; t < 4; ++t) { nu += w4[t] * P[c][t]; de += w4[t] * A[c][t]; }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float w = w_row<L>(utt, f0[c] + t)[k];
+            nu += w * P[c][t];
+            de += w * A[c][t];
+          }
         }
       }
     if (has_x) {
-      const float w = w_row<L>(utt, a.F - 1)[k];
+      const float w = L ? wl[k * a.Fs + a.F - 1] : w_row<L>(utt, a.F - 1)[k];
       nu += w * px;
       de += w * ax;
     }
@@ -412,6 +449,15 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
   using RBt = RowBatch<NCH, ST>;
   int n_beg, n_end;
   wave_frames(a.NT, n_beg, n_end);
+#if VN_HG_STAGGER > 0
+  {
+    // The wavefronts of a SIMD start together and do the same work per frame, so they would all load, then all
+    // compute, in convoy (T = T_mem + T_compute).  Stagger them by their hardware wave slot: slot i waits i quarter
+    // periods once, and the load phase of one then falls under the arithmetic of the others for the rest of the launch.
+    const unsigned slot = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11)) & 3u;     // HW_REG_HW_ID, wave_id[3:0]
+    for (unsigned k = 0; k < slot * VN_HG_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   const bool one = a.R <= RBt::RB;                    // the frame fits one batch: its rows are read once
   for (int n = n_beg; n < n_end; ++n) {
     const ST* base = reinterpret_cast<const ST*>(a.VsS) + (size_t)n * a.Rs * a.Fs;
