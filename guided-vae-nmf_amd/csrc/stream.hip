@@ -21,6 +21,9 @@
 #ifndef VN_WS_WAVES
 #define VN_WS_WAVES 4
 #endif
+#ifndef VN_HG_EXACT
+#define VN_HG_EXACT 0     // exact-sample-count instantiations of hg_stream: measured slower (the branch-free row loops spill at the 128-register cap: 0.32 vs 0.24 ms)
+#endif
 #ifndef VN_HG_STAGGER
 #define VN_HG_STAGGER 0     // s_sleep(127) units (8128 cycles each) per hardware wave slot at the start of hg_stream
 #endif
@@ -441,12 +444,13 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void 
   }
 }
 
-template <int NCH, int KP, typename ST>
+// RT > 0: exactly RT samples per frame (no per-row branch: 90 uniform branches per frame otherwise)
+template <int NCH, int KP, typename ST, int RT = 0>
 __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void hg_stream_kernel(const StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   FrameCtx<NCH, KP, ST> fc(a, wlds + (KP <= 8 ? (size_t)(threadIdx.x >> 6) * a.Fs * KP : 0));
   fc.stage_block_w();
-  using RBt = RowBatch<NCH, ST>;
+  using RBt = RowBatch<NCH, ST, 1, RT>;
   int n_beg, n_end;
   wave_frames(a.NT, n_beg, n_end);
 #if VN_HG_STAGGER > 0
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
         if (r0 > 0) rb.load(fc, base, srow, r0, a.R);
 #pragma unroll
         for (int r = 0; r < RBt::RB; ++r)
-          if (r < rb.nr) {
+          if (rb.on(r)) {
             f32x4 v[NCH];
             rb.get(r, v);
 #pragma unroll
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
         if (!one) rb.load(fc, base, srow, r0, a.R);
 #pragma unroll
         for (int r = 0; r < RBt::RB; ++r)
-          if (r < rb.nr) {
+          if (rb.on(r)) {
             f32x4 v[NCH];
             rb.get(r, v);
 #pragma unroll
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
       if (!one) rb.load(fc, base, srow, r0, a.R);
 #pragma unroll
       for (int r = 0; r < RBt::RB; r += 2) {
-        if (r + 1 < rb.nr) {
+        if (rb.on(r + 1)) {
           f32x4 v0[NCH], v1[NCH];
           rb.get(r, v0);
           rb.get(r + 1, v1);
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
               cl[c][t] += fast_log2(pp);
               cx[c][t] += (x0 + x1) * fast_rcp(pp);
             }
-        } else if (r < rb.nr) {
+        } else if (rb.on(r)) {
           f32x4 v0[NCH];
           rb.get(r, v0);
 #pragma unroll
@@ -1041,7 +1045,16 @@ int launch_st(StreamArgs a, int grid, hipStream_t st) {
     return 0;
   }
   if (KIND == SK_WSTATS) hipLaunchKernelGGL((wstats_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
-  else if (KIND == SK_HG) hipLaunchKernelGGL((hg_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
+  else if (KIND == SK_HG) {
+    constexpr int RBm = RowBatch<NCH, ST>::RB;
+    if (VN_HG_EXACT && NCH == 1 && KP <= 8 && a.R == 30 && RBm >= 30) {
+      if (int e = vn_ensure_dyn_lds((const void*)hg_stream_kernel<NCH, KP, ST, (RBm >= 30 && NCH == 1 ? 30 : 0)>, 80 * 1024)) return e;
+      hipLaunchKernelGGL((hg_stream_kernel<NCH, KP, ST, (RBm >= 30 && NCH == 1 ? 30 : 0)>), dim3(grid), dim3(256), lds, st, a);
+    } else if (VN_HG_EXACT && NCH == 1 && KP <= 8 && a.R == 10) {
+      if (int e = vn_ensure_dyn_lds((const void*)hg_stream_kernel<NCH, KP, ST, (RBm >= 10 && NCH == 1 ? 10 : 0)>, 80 * 1024)) return e;
+      hipLaunchKernelGGL((hg_stream_kernel<NCH, KP, ST, (RBm >= 10 && NCH == 1 ? 10 : 0)>), dim3(grid), dim3(256), lds, st, a);
+    } else hipLaunchKernelGGL((hg_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
+  }
   else hipLaunchKernelGGL((wf_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
   return 0;
 }
