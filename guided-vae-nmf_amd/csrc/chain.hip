@@ -31,6 +31,9 @@ __device__ long long g_wc_stamp[32];
 #define WC_STAMP(slot)
 #define WC_STAMP_FLUSH
 #endif
+#ifndef VN_TPR
+#define VN_TPR 1
+#endif
 #ifndef VN_VPER
 #define VN_VPER 6
 #endif
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
               __builtin_amdgcn_sched_group_barrier(0x402, VN_VPER, 0);    // VALU / transcendental
             }
           }
-          VN_SB;
+          if (VN_TPR <= 1 || (t % VN_TPR) == VN_TPR - 1 || t == N) VN_SB;      // VN_TPR tiles per scheduling region
         }
       };
       bf16x8 gfr[GT > 0 ? GT : 1][NK];                 // hi fragments of the bin tiles that live in global memory (L2)

@@ -271,8 +271,8 @@ struct RowBatch {
   // this lane's constant byte offset (one VGPR) + a scalar offset built from the row's slot -- no 64-bit address
   // pair per row in vector registers (thirty of them per frame spilled in the pipelined kernels).
   template <typename FC>
-  __device__ __forceinline__ void load_rows_buf(const FC& fc, __amdgpu_buffer_rsrc_t rs, unsigned frame_off, int sl, int R) {
-    nr = RT > 0 ? RT : (R < RB ? R : RB);
+  __device__ __forceinline__ void load_rows_buf(const FC& fc, __amdgpu_buffer_rsrc_t rs, unsigned frame_off, int sl, int R, int r0 = 0) {
+    nr = RT > 0 ? RT : (R - r0 < RB ? R - r0 : RB);
     const unsigned rowb = (unsigned)fc.a.Fs * (unsigned)sizeof(ST);
     // (raw bits: the conversion would wait for this load before the row loads below are even issued; finish_x()
     // converts at the first use, a frame later)
@@ -462,12 +462,14 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
     for (unsigned k = 0; k < slot * VN_HG_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
   }
 #endif
+  __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.VsS), 0, (int)((unsigned)a.NT * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST)), 0x00020000);
   const bool one = a.R <= RBt::RB;                    // the frame fits one batch: its rows are read once
   for (int n = n_beg; n < n_end; ++n) {
-    const ST* base = reinterpret_cast<const ST*>(a.VsS) + (size_t)n * a.Rs * a.Fs;
+    const unsigned foff = (unsigned)n * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST);      // (buffer-addressed rows: no 64-bit address pairs)
     const int32_t* srow = a.src + n;
     RBt rb;
-    rb.load(fc, base, srow, 0, a.R);
+    rb.load_rows_buf(fc, vrs, foff, RBt::load_slots(fc, srow, 0, a.R), a.R, 0);
+    rb.finish_x();
     const int utt = a.frame_utt[n];
     fc.set_utt(utt);
     const float gn = a.g[n];
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
 #pragma unroll
       for (int c = 0; c < NCH; ++c) a1[c] = a2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int r0 = 0; r0 < a.R; r0 += RBt::RB) {
-        if (r0 > 0) rb.load(fc, base, srow, r0, a.R);
+        if (r0 > 0) { rb.load_rows_buf(fc, vrs, foff, RBt::load_slots(fc, srow, r0, a.R), a.R, r0); rb.finish_x(); }
 #pragma unroll
         for (int r = 0; r < RBt::RB; ++r)
           if (rb.on(r)) {
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
 #pragma unroll
       for (int c = 0; c < NCH; ++c) ng[c] = dg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int r0 = 0; r0 < a.R; r0 += RBt::RB) {
-        if (!one) rb.load(fc, base, srow, r0, a.R);
+        if (!one) { rb.load_rows_buf(fc, vrs, foff, RBt::load_slots(fc, srow, r0, a.R), a.R, r0); rb.finish_x(); }
 #pragma unroll
         for (int r = 0; r < RBt::RB; ++r)
           if (rb.on(r)) {
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) cl[c] = cx[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int r0 = 0; r0 < a.R; r0 += RBt::RB) {
-      if (!one) rb.load(fc, base, srow, r0, a.R);
+      if (!one) { rb.load_rows_buf(fc, vrs, foff, RBt::load_slots(fc, srow, r0, a.R), a.R, r0); rb.finish_x(); }
 #pragma unroll
       for (int r = 0; r < RBt::RB; r += 2) {
         if (rb.on(r + 1)) {

@@ -237,12 +237,14 @@ class BatchEngine:
 
     def run(self, niter, nsE, biE, nsWF, biWF, var_rw, store=None):
         """Fused EM.run for the whole batch (device RNG).  Returns (cost [U,niter] float64, S_hat, N_hat).
-        store: use the sample-variance store (include/vaenmf.h); default: on in bf16 mode, off in bf16x3 mode."""
+        store: use the sample-variance store (include/vaenmf.h); default: on (bf16 rows in bf16 mode, float rows in
+        bf16x3 mode; vaenmf_em_run falls back to the decoding M-step when a batch's store would pass 3.5 GB --
+        VAENMF_Q_MSTEP_PATH tells which path ran)."""
         cost = torch.zeros(self.U, niter, device=self.device, dtype=torch.float64)
         S = torch.empty_like(self.X)
         N = torch.empty_like(self.X)
-        if store is None:       # bf16 mode: the chain keeps the samples' variances in HBM, M-step and Wiener filter stream them
-            store = self.precision == _lib.PREC_BF16 and self.F <= 769
+        if store is None:       # the chain keeps the samples' variances in HBM, M-step and Wiener filter stream them
+            store = self.F <= 769
         self.sample_store(store)
         check(lib().vaenmf_em_run(self._plan, _ptr(self.X2), _ptr(self.W), _ptr(self.Ht), _ptr(self.g), _ptr(self.Z),
                                   _ptr(self.B1), _ptr(self.Zs), self.Rcap, int(niter), int(nsE), int(biE), int(nsWF),

@@ -170,7 +170,7 @@ class _MCEM:
         if self.rng == "device":
             ns, bi = self.e_step_counts()
             nw, bw = self.wf_counts()
-            c, S, Nn = self._eng.run(self.niter, ns, bi, nw, bw, self.var_RW)
+            c, S, Nn = self._eng.run(self.niter, ns, bi, nw, bw, self.var_RW, store=False)      # (one utterance: the decoding M-step, bit-equal to the step-wise calls)
             cost[:] = c[0].cpu().numpy()
             self._R = nw
         else:

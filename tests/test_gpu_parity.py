@@ -277,7 +277,7 @@ def test_fused_run_equals_stepwise_and_batches_are_independent():
 
     niter, nsE, biE, nsW, biW = 3, 6, 5, 12, 7
     eng = prep([0, 1, 2])
-    cost, S, N = eng.run(niter, nsE, biE, nsW, biW, 0.01)
+    cost, S, N = eng.run(niter, nsE, biE, nsW, biW, 0.01, store=False)
     cost = cost.cpu().numpy()
     assert np.all(np.isfinite(cost)) and np.all(np.isfinite(S.cpu().numpy()))
     # step by step
@@ -293,9 +293,25 @@ def test_fused_run_equals_stepwise_and_batches_are_independent():
     assert np.max(np.abs(c2 - cost) / np.abs(cost)) < 1e-12
     # utterance 1 alone
     eng3 = prep([1])
-    cost3, S3, N3 = eng3.run(niter, nsE, biE, nsW, biW, 0.01)
+    cost3, S3, N3 = eng3.run(niter, nsE, biE, nsW, biW, 0.01, store=False)
     sl = eng.utt_slice(1)
     assert torch.equal(S[sl], S3) and np.array_equal(cost[1], cost3.cpu().numpy()[0])
+    # the same with the sample-variance store (the default of run()): fused == step-wise stored calls, bit for bit
+    eng4 = prep([0, 1, 2])
+    cost4, S4, N4 = eng4.run(niter, nsE, biE, nsW, biW, 0.01)
+    from vaenmf import _lib
+    assert _lib.lib().vaenmf_plan_query(eng4._plan, _lib.Q_MSTEP_PATH) == 1
+    eng5 = prep([0, 1, 2])
+    eng5.sample_store(True)
+    c5 = np.zeros((3, niter))
+    for it in range(niter):
+        eng5.mh_chain(nsE, biE, 0.01, call=it)
+        eng5.m_step_stored()
+        c5[:, it] = eng5.cost_from_frames(nsE)
+    eng5.mh_chain(nsW, biW, 0.01, call=niter, update_Z=False)
+    S5, N5, _, _ = eng5.wiener_stored()
+    assert torch.equal(S4, S5) and torch.equal(N4, N5)
+    assert np.max(np.abs(c5 - cost4.cpu().numpy()) / np.abs(c5)) < 1e-12
 
 
 def test_stft_istft_and_metrics():

@@ -46,7 +46,7 @@ def test_si_sdr_and_cost_distribution_match_reference():
     wav_x, wav_s, wav_n = rep(2), rep(0), rep(1)
     from vaenmf import _lib
     res = {}
-    for name, prec, store in (("bf16x3", "bf16x3", None), ("bf16 + bf16 sample store (bench mode)", "bf16", None), ("bf16, M-step decoding", "bf16", False)):
+    for name, prec, store in (("bf16x3", "bf16x3", False), ("bf16 + bf16 sample store (bench mode)", "bf16", None), ("bf16, M-step decoding", "bf16", False)):
         rec = Reconstructor(params, F, K, niter=NITER, fs=FS, wlen_sec=WLEN, precision=prec, device=dev,
                             max_frames=U * SB * (T // 128 + 8), max_utts=U * SB, store=store)
         sdrs, costs = [], []

@@ -8,7 +8,8 @@ def short(k):
     m = __import__("re").match(r"_ZN12_GLOBAL__N_1\d+(\w+?_kernel)I(.*?)EEv", k)      # names rocprofv3 left mangled
     if m: k = m.group(1) + "<" + m.group(2).replace("Li", "").replace("E", ",").replace("DF16b", "bf16").replace("f", "float").strip(",") + ">"
     return k[:90]
-st = glob.glob(os.path.join(src, "trace/*/*_kernel_stats.csv"))[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)      # (gpurun merges into an existing directory: take the latest run)
+st = newest(os.path.join(src, "trace/*/*_kernel_stats.csv"))
 P("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --precision", tag)
 P("# (per kernel: calls, total ms, average us, % of GPU kernel time)")
 for r in csv.DictReader(open(st)):
@@ -19,7 +20,7 @@ P("# bench line of the traced run:")
 P("# (tracing slows the host side: the traced step is longer than the kernels' sum; per-kernel launch times in the JSON come from HIP events)")
 P([l for l in open(os.path.join(src, "bench_trace.log")).read().splitlines() if l.startswith("{")][-1])
 def pmc(name):
-    f = glob.glob(os.path.join(src, name, "*/*_counter_collection.csv"))[0]
+    f = newest(os.path.join(src, name, "*/*_counter_collection.csv"))
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); nd = collections.defaultdict(set); dur = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
