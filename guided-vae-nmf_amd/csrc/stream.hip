@@ -462,14 +462,12 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
     for (unsigned k = 0; k < slot * VN_HG_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
   }
 #endif
-  __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.VsS), 0, (int)((unsigned)a.NT * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST)), 0x00020000);
   const bool one = a.R <= RBt::RB;                    // the frame fits one batch: its rows are read once
   for (int n = n_beg; n < n_end; ++n) {
-    const unsigned foff = (unsigned)n * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST);      // (buffer-addressed rows: no 64-bit address pairs)
+    const ST* base = reinterpret_cast<const ST*>(a.VsS) + (size_t)n * a.Rs * a.Fs;
     const int32_t* srow = a.src + n;
     RBt rb;
-    rb.load_rows_buf(fc, vrs, foff, RBt::load_slots(fc, srow, 0, a.R), a.R, 0);
-    rb.finish_x();
+    rb.load(fc, base, srow, 0, a.R);
     const int utt = a.frame_utt[n];
     fc.set_utt(utt);
     const float gn = a.g[n];
@@ -494,7 +492,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
 #pragma unroll
       for (int c = 0; c < NCH; ++c) a1[c] = a2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int r0 = 0; r0 < a.R; r0 += RBt::RB) {
-        if (r0 > 0) { rb.load_rows_buf(fc, vrs, foff, RBt::load_slots(fc, srow, r0, a.R), a.R, r0); rb.finish_x(); }
+        if (r0 > 0) rb.load(fc, base, srow, r0, a.R);
 #pragma unroll
         for (int r = 0; r < RBt::RB; ++r)
           if (rb.on(r)) {
@@ -548,7 +546,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
 #pragma unroll
       for (int c = 0; c < NCH; ++c) ng[c] = dg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int r0 = 0; r0 < a.R; r0 += RBt::RB) {
-        if (!one) { rb.load_rows_buf(fc, vrs, foff, RBt::load_slots(fc, srow, r0, a.R), a.R, r0); rb.finish_x(); }
+        if (!one) rb.load(fc, base, srow, r0, a.R);
 #pragma unroll
         for (int r = 0; r < RBt::RB; ++r)
           if (rb.on(r)) {
@@ -588,7 +586,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) cl[c] = cx[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int r0 = 0; r0 < a.R; r0 += RBt::RB) {
-      if (!one) { rb.load_rows_buf(fc, vrs, foff, RBt::load_slots(fc, srow, r0, a.R), a.R, r0); rb.finish_x(); }
+      if (!one) rb.load(fc, base, srow, r0, a.R);
 #pragma unroll
       for (int r = 0; r < RBt::RB; r += 2) {
         if (rb.on(r + 1)) {
