@@ -434,6 +434,66 @@ def test_m_step_and_chain_other_shapes(F, K, R, model):
             assert np.max(np.abs(eng.Zs[sl, :ns].cpu().numpy() - Zs_ref)) < 1e-5
 
 
+@pytest.mark.parametrize("F,model", [(257, "M1"), (513, "M1"), (257, "M2"), (65, "M1")])
+def test_wave_chain_bf16_mode(F, model):
+    """The wave-private chain kernel in bf16 mode (8 wavefronts per workgroup at F=257; 4 with four W3 tiles streamed
+    from L2 at F=513; 4 with the per-frame layer-1 bias for M2) on a ragged batch with replayed noise:
+    every log-acceptance (mcem.py:415-417) within 0.5 of the fp32 oracle's (bf16 products: ~1 % on each of F
+    variances) and within 0.1 of the round-1 team kernel's (same bf16 operands, other summation order; its odd last bin
+    is an fp32 dot product); where both kernels decide every step alike the samples agree to fma rounding."""
+    need_gpu()
+    Dy = 1 if model == "M2" else 0
+    K, ns, S_steps = 8, 3, 6
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=11, y_dim=Dy, bias_std=0.05)
+    counts = [21, 40, 9]
+    g = np.random.default_rng(F + 3)
+    Xs = [((g.standard_normal((n, F)) + 1j * g.standard_normal((n, F))) * (0.5 + 3 * np.exp(-np.arange(F) / 60.0))).astype(np.complex64) for n in counts]
+    W0 = [np.maximum(g.random((F, K)), 1e-8).astype(np.float32) for _ in counts]
+    H0 = [np.maximum(g.random((K, n)), 1e-8).astype(np.float32) for n in counts]
+    ys = [(g.random((n, Dy)) > 0.5).astype(np.float32) for n in counts] if Dy else [None] * 3
+    NT = sum(counts)
+    eps = g.standard_normal((S_steps, NT, 32)).astype(np.float32)
+    uu = g.random((S_steps, NT)).astype(np.float32)
+    Z0 = (0.5 * g.standard_normal((NT, 32))).astype(np.float32)
+    gains = (0.5 + g.random(NT)).astype(np.float32)
+    out = {}
+    for kern in ("wave", "team"):
+        os.environ["VAENMF_TEAM_CHAIN"] = "1" if kern == "team" else "0"
+        try:
+            eng = make_engine(params, F, K, counts, Rcap=ns, precision="bf16")
+            eng.set_spectrogram(Xs)
+            eng.init_nmf(W0, H0)
+            if Dy:
+                eng.set_labels(torch.from_numpy(np.concatenate(ys)))
+            eng.g.copy_(torch.from_numpy(gains))
+            eng.Z.copy_(torch.from_numpy(Z0))
+            acc = eng.mh_chain(ns, S_steps - ns, 0.01, eps=torch.from_numpy(eps).to(eng.device), u=torch.from_numpy(uu).to(eng.device),
+                               want_acc=True).cpu().numpy()
+            out[kern] = (acc, eng.Zs[:, :ns].cpu().numpy().copy(), eng.Z.cpu().numpy().copy())
+        finally:
+            os.environ.pop("VAENMF_TEAM_CHAIN", None)
+    assert np.all(np.isfinite(out["wave"][0]))
+    assert np.max(np.abs(out["wave"][0] - out["team"][0])) < 0.1
+    same = np.all((np.log(uu) < out["wave"][0]) == (np.log(uu) < out["team"][0]), axis=0)
+    assert same.mean() > 0.9
+    assert np.max(np.abs(out["wave"][1][same] - out["team"][1][same])) < 1e-5 and np.max(np.abs(out["wave"][2][same] - out["team"][2][same])) < 1e-5
+    off = np.concatenate([[0], np.cumsum(counts)])
+    for u, n in enumerate(counts):
+        sl = slice(off[u], off[u + 1])
+        o = orc.MCEMOracle(model, 1)
+        o.init_parameters(Xs[u], params, K, 1e-8, orc.NumpyRNG(0), y=ys[u], W0=W0[u], H0=H0[u])
+        o.g = gains[sl].copy()
+        draws = []
+        for m in range(S_steps):
+            draws += [eps[m, sl].T.copy(), uu[m, sl].copy()]
+        o.rng = orc.ReplayRNG(draws)
+        tr = []
+        o.sample_posterior(Z0[sl].T.copy(), ns, S_steps - ns, trace=tr)
+        ref = np.stack([t["acc"] for t in tr])
+        # (only the first step is comparable for every frame: afterwards a chain whose decision differs is in another state)
+        assert np.max(np.abs(out["wave"][0][0, sl] - ref[0])) < 0.5
+
+
 def test_classifier_labels():
     """scripts/evaluate_M2_vad.py:122-131: (x-mean^T)/(std+eps)^T -> Classifier -> > 0.5."""
     need_gpu()
