@@ -21,6 +21,9 @@
 #ifndef VN_WS_WAVES
 #define VN_WS_WAVES 4
 #endif
+#ifndef VN_ROWCHUNK
+#define VN_ROWCHUNK 1      // rows per uniform branch in RowBatch::for_rows (2, 3, 5 rows per branch spill more at the 128-register cap: 87 / 106 / 275 scratch operations against 50)
+#endif
 #ifndef VN_HG_EXACT
 #define VN_HG_EXACT 0     // exact-sample-count instantiations of hg_stream: measured slower (the branch-free row loops spill at the 128-register cap: 0.32 vs 0.24 ms)
 #endif
@@ -293,6 +296,24 @@ struct RowBatch {
         }
       }
   }
+  // f(r) for every row of the batch, r a compile-time constant after unrolling.  Runtime row counts: one uniform
+  // branch per CHUNK of rows instead of one per row (90 branches per frame in hg_stream, each ending a scheduling
+  // region and a precise vmcnt count); only the last, partial chunk checks row by row.
+  template <typename FN>
+  __device__ __forceinline__ void for_rows(FN f) const {
+    constexpr int CH = VN_ROWCHUNK;
+#pragma unroll
+    for (int r0 = 0; r0 < RB; r0 += CH) {
+      if (RT > 0 ? r0 + CH <= RT : r0 + CH <= nr) {
+#pragma unroll
+        for (int r = r0; r < r0 + CH && r < RB; ++r) f(r);
+      } else {
+#pragma unroll
+        for (int r = r0; r < r0 + CH && r < RB; ++r)
+          if (on(r)) f(r);
+      }
+    }
+  }
   __device__ __forceinline__ void finish_x() {        // after load_rows_buf: extra-bin bits -> float
     if constexpr (sizeof(ST) == 2) xr = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, xr) << 16);
   }
@@ -493,20 +514,19 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
       for (int c = 0; c < NCH; ++c) a1[c] = a2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int r0 = 0; r0 < a.R; r0 += RBt::RB) {
         if (r0 > 0) rb.load(fc, base, srow, r0, a.R);
+        auto row1 = [&](int r) {
+          f32x4 v[NCH];
+          rb.get(r, v);
 #pragma unroll
-        for (int r = 0; r < RBt::RB; ++r)
-          if (rb.on(r)) {
-            f32x4 v[NCH];
-            rb.get(r, v);
+          for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
-#pragma unroll
-              for (int t = 0; t < 4; ++t) {
-                const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
-                a1[c][t] += q;
-                a2[c][t] += q * q;
-              }
-          }
+            for (int t = 0; t < 4; ++t) {
+              const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
+              a1[c][t] += q;
+              a2[c][t] += q * q;
+            }
+        };
+        rb.for_rows(row1);
         const float q = fast_rcp(gn * rb.xr + vbx) * rb.xmask(fc);
         a1x += wave_sum(q);
         a2x += wave_sum(q * q);
@@ -547,21 +567,20 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
       for (int c = 0; c < NCH; ++c) ng[c] = dg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int r0 = 0; r0 < a.R; r0 += RBt::RB) {
         if (!one) rb.load(fc, base, srow, r0, a.R);
+        auto row2 = [&](int r) {
+          f32x4 v[NCH];
+          rb.get(r, v);
 #pragma unroll
-        for (int r = 0; r < RBt::RB; ++r)
-          if (rb.on(r)) {
-            f32x4 v[NCH];
-            rb.get(r, v);
+          for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
-#pragma unroll
-              for (int t = 0; t < 4; ++t) {
-                const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
-                const float vq = v[c][t] * q;
-                dg[c][t] += vq;                 // sum_r Vs / Vx
-                ng[c][t] += vq * q;             // sum_r Vs / Vx^2
-              }
-          }
+            for (int t = 0; t < 4; ++t) {
+              const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
+              const float vq = v[c][t] * q;
+              dg[c][t] += vq;                 // sum_r Vs / Vx
+              ng[c][t] += vq * q;             // sum_r Vs / Vx^2
+            }
+        };
+        rb.for_rows(row2);
         const float q = fast_rcp(gn * rb.xr + vbx), vq = rb.xr * q * rb.xmask(fc);
         dgx += wave_sum(vq);
         ngx += wave_sum(vq * q);
