@@ -948,6 +948,44 @@ def test_stored_path_with_labels_and_fixed_noise(variant):
     assert nrm_err(Sb.cpu().numpy(), Sa.cpu().numpy()) < 1e-2 and nrm_err(Nb.cpu().numpy(), Na.cpu().numpy()) < 1e-2
 
 
+@pytest.mark.parametrize("F,K", [(257, 8), (513, 10)])
+def test_bench_mode_m_step_against_the_oracle(F, K):
+    """The bench mode's M-step -- bf16 MFMA chain, sample variances stored as bf16 rows, streaming W / H / g / cost
+    kernels -- against the fp32 ORACLE's M-step (mcem.py:90-152) from the same posterior samples (the chain's own Zs,
+    decoded by the oracle in fp32).  Stated bounds: W, H, g within 3e-2 relative (bf16 products carry ~1 % on each
+    variance, bf16 storage 0.4 %; every update is a ratio of sums over 30 samples x F bins), cost within 3e-3."""
+    need_gpu()
+    R, bi = 30, 4
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=5, bias_std=0.05)
+    counts = [21, 40, 9]
+    g = np.random.default_rng(F * 3 + K)
+    Xs = [((g.standard_normal((n, F)) + 1j * g.standard_normal((n, F))) * (0.5 + 3 * np.exp(-np.arange(F) / 60.0))).astype(np.complex64) for n in counts]
+    W0 = [np.maximum(g.random((F, K)), 1e-8).astype(np.float32) for _ in counts]
+    H0 = [np.maximum(g.random((K, n)), 1e-8).astype(np.float32) for n in counts]
+    eng = make_engine(params, F, K, counts, Rcap=R, precision="bf16", seeds=[3, 4, 5])
+    eng.set_spectrogram(Xs)
+    eng.init_nmf(W0, H0)
+    gains = (0.5 + g.random(sum(counts))).astype(np.float32)
+    eng.g.copy_(torch.from_numpy(gains))
+    eng.Z.copy_(torch.from_numpy((0.5 * g.standard_normal((sum(counts), 32))).astype(np.float32)))
+    eng.sample_store(True)
+    eng.mh_chain(R, bi, 0.01, call=0)
+    Zs = eng.Zs[:, :R].cpu().numpy()
+    eng.m_step_stored()
+    cost = eng.cost_from_frames(R)
+    for u, n in enumerate(counts):
+        sl = eng.utt_slice(u)
+        o = orc.MCEMOracle("M1", 1)
+        o.init_parameters(Xs[u], params, K, 1e-8, orc.NumpyRNG(0), W0=W0[u], H0=H0[u])
+        o.g = gains[sl].copy()
+        o.compute_Vs(Zs[sl]); o.compute_Vs_scaled(); o.compute_Vx()
+        o.M_step()
+        assert rel_err(eng.W[u, :F, :K].cpu().numpy(), o.W) < 3e-2
+        assert rel_err(eng.Ht[sl, :K].cpu().numpy().T, o.H) < 3e-2
+        assert rel_err(eng.g[sl].cpu().numpy(), o.g) < 3e-2
+        assert abs(cost[u] - o.compute_expected_neg_log_like()) / abs(cost[u]) < 3e-3
+
+
 def test_fused_run_with_the_sample_store():
     """vaenmf_em_run with the store on (chain stores, streaming M-step and Wiener filter) against the run that
     decodes the samples again: same device RNG streams; the trajectories agree to rounding for the first
