@@ -31,6 +31,9 @@ __device__ long long g_wc_stamp[32];
 #define WC_STAMP(slot)
 #define WC_STAMP_FLUSH
 #endif
+#ifndef VN_PF
+#define VN_PF 1
+#endif
 #ifndef VN_TPR
 #define VN_TPR 1
 #endif
@@ -286,26 +289,31 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
       //   NKS k-steps; frag(t, s, hi, lo) loads; bias(t); bop(s, hi, lo) the input fragments; epi(t, acc)
       auto run_layer = [&](auto nks_c, auto ntiles_c, auto frag, auto bias, auto bop, auto epi) {
         constexpr int NKS = decltype(nks_c)::value, N = decltype(ntiles_c)::value;
-        bf16x8 wh[2][NKS], wl[2][NKS];
-        f32x4 acc[2], bnext;
+        // VN_PF tiles of weight fragments (and bias) in flight ahead of the MFMAs that use them
+        constexpr int PF = VN_PF, NB = PF + 1;
+        bf16x8 wh[NB][NKS], wl[NB][NKS];
+        f32x4 acc[2], bq[NB];
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) frag(0, s, wh[0][s], wl[0][s]);
-        bnext = bias(0);
+        for (int p = 0; p < PF; ++p)
+          if (p < N) {
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) frag(p, s, wh[p % NB][s], wl[p % NB][s]);
+            bq[p % NB] = bias(p);
+          }
 #pragma unroll
         for (int t = 0; t <= N; ++t) {
-          const f32x4 bcur = bnext;
-          if (t + 1 < N && tile_on3(N, t + 1)) {
+          if (t + PF < N && tile_on3(N, t + PF)) {
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) frag(t + 1, s, wh[(t + 1) & 1][s], wl[(t + 1) & 1][s]);
-            bnext = bias(t + 1);
+            for (int s = 0; s < NKS; ++s) frag(t + PF, s, wh[(t + PF) % NB][s], wl[(t + PF) % NB][s]);
+            bq[(t + PF) % NB] = bias(t + PF);
           }
           if (t < N && tile_on3(N, t)) {
-            f32x4 ac = bcur;
+            f32x4 ac = bq[t % NB];
 #pragma unroll
             for (int s = 0; s < NKS; ++s) {
               bf16x8 ah, al;
               bop(s, ah, al);
-              ac = mma<SPLIT>(wh[t & 1][s], wl[t & 1][s], ah, al, ac);
+              ac = mma<SPLIT>(wh[t % NB][s], wl[t % NB][s], ah, al, ac);
             }
             acc[t & 1] = ac;
           }
