@@ -73,6 +73,7 @@ struct WcArgs {
   const float *eps, *u;            // replay draws or null
   int Kp, NT, Rcap, nsamples, burnin, rng_mode, update_Z;
   int n_hi_lds;                    // W3 tiles whose hi fragments are in LDS (the rest streams from L2)
+  int b1_lds;                      // M2 at 8 wavefronts: byte offset of the per-wave stash of the layer-1 bias rows
   uint32_t call;
   float sd;
 };
@@ -129,7 +130,9 @@ __device__ __forceinline__ f32x4 mma(const bf16x8 whi, const bf16x8 wlo, const b
 // GT   : the hi fragments of the FIRST GT bin tiles stay in global memory (F = 513: W3 does not fit the LDS whole); a
 //        wavefront requests them at the top of every evaluation, two layers before their use, and before any store of
 //        that evaluation (vmcnt counts in order); LDS holds tiles GT..NT3-1
-// M2   : per-frame layer-1 bias B1 = b1 + W1[:, L:] y_n (kept in registers), else b1 from LDS
+// M2   : per-frame layer-1 bias B1 = b1 + W1[:, L:] y_n, else b1 from LDS.  At 4 wavefronts (512 registers each) the
+//        lane's 32 values stay in registers; at 8 (bf16 mode, 256 registers) each lane parks them as bf16 in a private
+//        8 x 8 bytes of LDS (4 KB per wavefront) and reads one 8-byte word back per layer-1 tile
 template <int MAXT, bool EXACT, bool SPLIT, bool STORE, int NWAVES, bool LOL, bool HIALL, bool M2, int GT>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const WcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -227,10 +230,16 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
         vb[t] = v;
       }
     }
-    f32x4 b1r[M2 ? NTH : 1];                               // M2: layer-1 accumulator init of this lane's frame
+    constexpr bool B1L = M2 && NWAVES == 8;                // layer-1 bias rows parked in LDS (see above)
+    f32x4 b1r[(M2 && !B1L) ? NTH : 1];                     // M2: layer-1 accumulator init of this lane's frame
+    char* b1stash = smem + a.b1_lds + wave * (NTH * 512) + lane * 8;     // [tile][lane][4 bf16], this lane's words only
     if (M2) {
 #pragma unroll
-      for (int t = 0; t < NTH; ++t) b1r[M2 ? t : 0] = *reinterpret_cast<const f32x4*>(a.B1 + (size_t)nrow * HID + 16 * t + 4 * q);
+      for (int t = 0; t < NTH; ++t) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.B1 + (size_t)nrow * HID + 16 * t + 4 * q);
+        if (B1L) *reinterpret_cast<u32x2*>(b1stash + t * 512) = u32x2{pk2(v[0], v[1]), pk2(v[2], v[3])};
+        else b1r[(M2 && !B1L) ? t : 0] = v;
+      }
     }
     // ---- current latent state, fragment order: latents 4q..4q+3 and 16+4q..16+4q+3 of frame c
     float z[8];
@@ -354,7 +363,13 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
                     hi = *reinterpret_cast<const bf16x8*>(p);
                     lo = SPLIT ? *reinterpret_cast<const bf16x8*>(p + 1024) : hi;
                   },
-                  [&](int t) { return M2 ? b1r[M2 ? t : 0] : *reinterpret_cast<const f32x4*>(b1l + 16 * t + 4 * q); },
+                  [&](int t) {
+                    if (B1L) {
+                      const u32x2 w = *reinterpret_cast<const u32x2*>(b1stash + t * 512);
+                      return f32x4{bf_lo(w[0]), bf_hi(w[0]), bf_lo(w[1]), bf_hi(w[1])};
+                    }
+                    return M2 ? b1r[(M2 && !B1L) ? t : 0] : *reinterpret_cast<const f32x4*>(b1l + 16 * t + 4 * q);
+                  },
                   [&](int, bf16x8& hi, bf16x8& lo) { hi = __builtin_bit_cast(bf16x8, bh[0]); lo = SPLIT ? __builtin_bit_cast(bf16x8, bl[0]) : hi; },
                   [&](int t, const f32x4 acc) { put(ch, cl, t, tanh4(acc)); });
       }
@@ -534,16 +549,16 @@ int wc_launch(const WcArgs& a, int grid, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL(fn, dim3(grid), dim3(NWAVES * 64), lds, st, a);
   return 0;
 }
-// M1 runs NW1 wavefronts per workgroup, M2 (32 more registers: the per-frame layer-1 bias) always 4
+// M1 runs NW1 wavefronts per workgroup; M2 the same (at 8 the per-frame layer-1 bias rows live in LDS: b1_lds)
 template <int MAXT, bool EXACT, bool SPLIT, int NW1, bool LOL, int GT = 0>
 int wc_launch_s(const WcArgs& a, int nwt, int n_sms, size_t lds, hipStream_t st) {
-  const int nw = a.B1 ? 4 : NW1;
+  const int nw = NW1;
   int grid = (nwt + nw - 1) / nw;
   if (grid > n_sms) grid = n_sms;                       // one workgroup per CU (LDS), wave tiles in a grid-stride loop
   if (a.B1) {
 #if !defined(VN_DEV_FAST) || defined(VN_DEV_M2)
-    return a.VsS ? wc_launch<MAXT, EXACT, SPLIT, true, 4, LOL, true, true, GT>(a, grid, lds, st)
-                 : wc_launch<MAXT, EXACT, SPLIT, false, 4, LOL, true, true, GT>(a, grid, lds, st);
+    return a.VsS ? wc_launch<MAXT, EXACT, SPLIT, true, NW1, LOL, true, true, GT>(a, grid, lds, st)
+                 : wc_launch<MAXT, EXACT, SPLIT, false, NW1, LOL, true, true, GT>(a, grid, lds, st);
 #else
     return -1;
 #endif
@@ -580,10 +595,12 @@ int vn_launch_wchain(vaenmf_plan* p, const VnChainCall& cc, hipStream_t st) {
   constexpr int GT33 = 4;                                // F = 513: bin tiles whose fragments stay in global memory
   const size_t w3hi = (size_t)(p->NT3c == 33 ? p->NT3c - GT33 : p->NT3c) * NK * 1024;
   const bool lol = split && p->NT3c <= 5;              // bf16x3: the lo fragments of W3 fit in LDS up to 5 tiles (F <= 80), else they stream from L2
-  const size_t lds = fixed + w3hi * (lol ? 2 : 1);
+  constexpr int NW_BF16 = VN_WC_WAVES_BF16, NW_X3 = 4;
+  const int nwaves = (split || p->NT3c == 33) ? 4 : NW_BF16;
+  a.b1_lds = (int)(fixed + w3hi * (lol ? 2 : 1));
+  const size_t lds = (size_t)a.b1_lds + ((cc.B1 && nwaves == 8) ? (size_t)nwaves * NTH * 512 : 0);
   VN_REQUIRE(lds <= (size_t)WC_LDS_LIMIT, "wave chain: %zu bytes of LDS needed", lds);
   // wavefronts per workgroup: 8 (two per SIMD, 256 registers each) in bf16 mode, 4 (512 registers) in bf16x3 mode
-  constexpr int NW_BF16 = VN_WC_WAVES_BF16, NW_X3 = 4;
   int rc = -1;
   if (p->NT3c == 33)     rc = wc_launch_s<33, true, false, 4, false, GT33>(a, p->n_wtiles, p->n_sms, lds, st);
   else if (p->NT3c == 17) rc = split ? wc_launch_s<17, true, true, NW_X3, false>(a, p->n_wtiles, p->n_sms, lds, st) : wc_launch_s<17, true, false, NW_BF16, false>(a, p->n_wtiles, p->n_sms, lds, st);

@@ -473,7 +473,9 @@ def test_wave_chain_bf16_mode(F, model):
         finally:
             os.environ.pop("VAENMF_TEAM_CHAIN", None)
     assert np.all(np.isfinite(out["wave"][0]))
-    assert np.max(np.abs(out["wave"][0] - out["team"][0])) < 0.1
+    # (M2 at 8 wavefronts keeps the per-frame layer-1 bias rows as bf16 in LDS -- one more 2^-9 rounding on the layer-1
+    # pre-activations, the size of the bf16 activation rounding the mode has anyway; the team kernel adds them in fp32)
+    assert np.max(np.abs(out["wave"][0] - out["team"][0])) < (0.2 if model == "M2" else 0.1)
     same = np.all((np.log(uu) < out["wave"][0]) == (np.log(uu) < out["team"][0]), axis=0)
     assert same.mean() > 0.9
     assert np.max(np.abs(out["wave"][1][same] - out["team"][1][same])) < 1e-5 and np.max(np.abs(out["wave"][2][same] - out["team"][2][same])) < 1e-5
