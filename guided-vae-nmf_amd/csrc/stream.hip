@@ -30,6 +30,9 @@
 #ifndef VN_HG_STAGGER
 #define VN_HG_STAGGER 0     // s_sleep(127) units (8128 cycles each) per hardware wave slot at the start of hg_stream
 #endif
+#ifndef VN_HG_PROBE
+#define VN_HG_PROBE 0     // dev probes of hg_stream: 1 = rows loaded, arithmetic reduced to one add per element; 2 = every row read from the same cached address
+#endif
 #ifndef VN_HG_REPACK
 #define VN_HG_REPACK 1
 #endif
@@ -78,7 +81,11 @@ struct FrameCtx {
   //              prologue when it fits); a wavefront in another utterance reads global memory.
   static constexpr bool WPRIV = KP <= 8;
   float* wl;                   // [Fs][KP]
-  int wutt, blk_utt;
+  // W[utt][F-1][k] of the extra bin in lane k (refreshed when the wavefront enters another utterance): its eight LDS
+  // addresses, loop-invariant, were spilled and every reload (scratch: a memory round trip, waited for with vmcnt(0))
+  // stalled the wavefront -- ~25 serial round trips per frame, more than the frame's arithmetic
+  float wx;
+  int wutt, blk_utt, xutt;
   bool in_lds;                 // wave-uniform: this frame's W rows are the ones in LDS
   __device__ FrameCtx(const StreamArgs& a_, float* wl_) : a(a_), wl(wl_) {
     lane = threadIdx.x & 63;
@@ -87,7 +94,12 @@ struct FrameCtx {
     has_x = a.F != a.Fm;
     wutt = -1;
     blk_utt = -1;
+    xutt = -1;
+    wx = 0.f;
     in_lds = false;
+  }
+  __device__ __forceinline__ float wxk(int k) const {       // W[utt][F-1][k], wave-uniform (k: compile time)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wx), k));
   }
   // workgroup prologue (rank > 8): stage W of the utterance of the workgroup's first frame
   __device__ __forceinline__ void stage_block_w() {
@@ -102,6 +114,10 @@ struct FrameCtx {
     __syncthreads();
   }
   __device__ __forceinline__ void set_utt(int utt) {        // wave-uniform
+    if (utt != xutt) {
+      xutt = utt;
+      wx = (has_x && lane < KP) ? a.W[((size_t)utt * a.Fs + a.F - 1) * KP + lane] : 0.f;
+    }
     if (!WPRIV) { in_lds = utt == blk_utt; return; }
     in_lds = true;
     if (utt == wutt) return;
@@ -142,7 +158,7 @@ struct FrameCtx {
       if (has_x) {
         float v = 0.f;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) v += wl[k * a.Fs + a.F - 1] * h[k];
+        for (int k = 0; k < KP; ++k) v += wxk(k) * h[k];
         vbx = v;
       }
       return;
@@ -166,10 +182,9 @@ struct FrameCtx {
     }
     vbx = 1.f;
     if (has_x) {
-      const float* wrow = w_row<L>(utt, a.F - 1);
       float v = 0.f;
 #pragma unroll
-      for (int k = 0; k < KP; ++k) v += wrow[k] * h[k];
+      for (int k = 0; k < KP; ++k) v += wxk(k) * h[k];
       vbx = v;
     }
   }
@@ -199,7 +214,7 @@ struct FrameCtx {
         }
       }
     if (has_x) {
-      const float w = L ? wl[k * a.Fs + a.F - 1] : w_row<L>(utt, a.F - 1)[k];
+      const float w = wxk(k);
       nu += w * px;
       de += w * ax;
     }
@@ -229,6 +244,10 @@ struct FrameCtx {
     if (a.Fm + lane < a.Fs) dst[a.Fm + lane] = (lane == 0 && has_x) ? vx : 0.f;
   }
 };
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 rcp2(const f32x2 x) { return f32x2{fast_rcp(x[0]), fast_rcp(x[1])}; }
+__device__ __forceinline__ f32x2 log2_2(const f32x2 x) { return f32x2{fast_log2(x[0]), fast_log2(x[1])}; }
 
 // A batch of up to RB rows of one frame in registers (this lane's bins, still packed as stored): every load of
 // the batch is issued before the first use, so a wavefront keeps RB x 0.5-1 KiB in flight -- the kernels are
@@ -261,7 +280,11 @@ struct RowBatch {
 #pragma unroll
     for (int r = 0; r < RB; ++r)
       if (on(r)) {
+#if VN_HG_PROBE == 2
+        const ST* row = reinterpret_cast<const ST*>(fc.a.VsS) + (size_t)(__builtin_amdgcn_readlane(sl, r) & 1) * fc.a.Fs;
+#else
         const ST* row = base + (size_t)__builtin_amdgcn_readlane(sl, r) * fc.a.Fs;
+#endif
 #pragma unroll
         for (int c = 0; c < NCH; ++c) raw[r][c] = *reinterpret_cast<const raw_t*>(row + (fc.cv[c] ? fc.f0[c] : 0));
       }
@@ -388,13 +411,12 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void 
             f32x4 v[NCH];
             hb.get(r, v);
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
-#pragma unroll
-              for (int t = 0; t < 4; ++t) {
-                const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
-                a1[c][t] += q;
-                a2[c][t] += q * q;
-              }
+            for (int c = 0; c < NCH; ++c) {
+              const f32x2 g2 = {gn, gn};
+              const f32x2 q0 = rcp2(g2 * v[c].lo + vb[c].lo), q1 = rcp2(g2 * v[c].hi + vb[c].hi);
+              a1[c].lo += q0; a1[c].hi += q1;
+              a2[c].lo = q0 * q0 + a2[c].lo; a2[c].hi = q1 * q1 + a2[c].hi;
+            }
           }
         const float q = fast_rcp(gn * hb.xr + vbx) * hb.xmask(fc);
         a1x += wave_sum(q);
@@ -444,13 +466,12 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void 
           f32x4 v[NCH];
           rb.get(r, v);
 #pragma unroll
-          for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
-              a1[c][t] += q;
-              a2[c][t] += q * q;
-            }
+          for (int c = 0; c < NCH; ++c) {
+            const f32x2 g2 = {gn, gn};
+            const f32x2 q0 = rcp2(g2 * v[c].lo + vb[c].lo), q1 = rcp2(g2 * v[c].hi + vb[c].hi);
+            a1[c].lo += q0; a1[c].hi += q1;
+            a2[c].lo = q0 * q0 + a2[c].lo; a2[c].hi = q1 * q1 + a2[c].hi;
+          }
         }
       const float q = fast_rcp(gn * rb.xr + vbx) * rb.xmask(fc);
       a1x += wave_sum(q);
@@ -492,6 +513,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
     const int utt = a.frame_utt[n];
     fc.set_utt(utt);
     const float gn = a.g[n];
+    const f32x2 gn2 = {gn, gn};
     f32x4 vb[NCH], x2[NCH];
     float vbx, x2x;
     fc.load_x2(n, x2, x2x);
@@ -517,14 +539,19 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
         auto row1 = [&](int r) {
           f32x4 v[NCH];
           rb.get(r, v);
+#if VN_HG_PROBE == 1
 #pragma unroll
-          for (int c = 0; c < NCH; ++c)
+          for (int c = 0; c < NCH; ++c) { a1[c] += v[c]; a2[c] += v[c]; }
+          return;
+#endif
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
-              a1[c][t] += q;
-              a2[c][t] += q * q;
-            }
+          for (int c = 0; c < NCH; ++c) {
+            // two bins per instruction (v_pk_fma / v_pk_add_f32: next to transcendentals a packed instruction costs the
+            // issue slot of a plain one -- tools/ubench/overlap.hip)
+            const f32x2 q0 = rcp2(gn2 * v[c].lo + vb[c].lo), q1 = rcp2(gn2 * v[c].hi + vb[c].hi);
+            a1[c].lo += q0; a1[c].hi += q1;
+            a2[c].lo = q0 * q0 + a2[c].lo; a2[c].hi = q1 * q1 + a2[c].hi;
+          }
         };
         rb.for_rows(row1);
         const float q = fast_rcp(gn * rb.xr + vbx) * rb.xmask(fc);
@@ -570,15 +597,18 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
         auto row2 = [&](int r) {
           f32x4 v[NCH];
           rb.get(r, v);
+#if VN_HG_PROBE == 1
 #pragma unroll
-          for (int c = 0; c < NCH; ++c)
+          for (int c = 0; c < NCH; ++c) { dg[c] += v[c]; ng[c] += v[c]; }
+          return;
+#endif
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
-              const float vq = v[c][t] * q;
-              dg[c][t] += vq;                 // sum_r Vs / Vx
-              ng[c][t] += vq * q;             // sum_r Vs / Vx^2
-            }
+          for (int c = 0; c < NCH; ++c) {
+            const f32x2 q0 = rcp2(gn2 * v[c].lo + vb[c].lo), q1 = rcp2(gn2 * v[c].hi + vb[c].hi);
+            const f32x2 vq0 = v[c].lo * q0, vq1 = v[c].hi * q1;
+            dg[c].lo += vq0; dg[c].hi += vq1;                                   // sum_r Vs / Vx
+            ng[c].lo = vq0 * q0 + ng[c].lo; ng[c].hi = vq1 * q1 + ng[c].hi;     // sum_r Vs / Vx^2
+          }
         };
         rb.for_rows(row2);
         const float q = fast_rcp(gn * rb.xr + vbx), vq = rb.xr * q * rb.xmask(fc);
@@ -597,6 +627,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
     }
     const float gnew = gn * __builtin_amdgcn_sqrtf(nu * fast_rcp(de));                     // mcem.py:142
     if (fc.lane == 0) a.g[n] = gnew;
+    const f32x2 gw2 = {gnew, gnew};
     if (one && VN_HG_REPACK) rb.repack();
     // ---- cost (mcem.py:70) with the refreshed variances (:151-152); samples two at a time:
     // log Vx0 + log Vx1 = log(Vx0 Vx1), 1/Vx0 + 1/Vx1 = (Vx0 + Vx1)/(Vx0 Vx1)
@@ -608,30 +639,28 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
       if (!one) rb.load(fc, base, srow, r0, a.R);
 #pragma unroll
       for (int r = 0; r < RBt::RB; r += 2) {
+        if (VN_HG_PROBE == 1) continue;
         if (rb.on(r + 1)) {
           f32x4 v0[NCH], v1[NCH];
           rb.get(r, v0);
           rb.get(r + 1, v1);
 #pragma unroll
-          for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float x0 = gnew * v0[c][t] + vb[c][t], x1 = gnew * v1[c][t] + vb[c][t];
-              const float pp = x0 * x1;
-              cl[c][t] += fast_log2(pp);
-              cx[c][t] += (x0 + x1) * fast_rcp(pp);
-            }
+          for (int c = 0; c < NCH; ++c) {
+            const f32x2 xa0 = gw2 * v0[c].lo + vb[c].lo, xa1 = gw2 * v1[c].lo + vb[c].lo;
+            const f32x2 xb0 = gw2 * v0[c].hi + vb[c].hi, xb1 = gw2 * v1[c].hi + vb[c].hi;
+            const f32x2 pa = xa0 * xa1, pb = xb0 * xb1;
+            cl[c].lo += log2_2(pa); cl[c].hi += log2_2(pb);
+            cx[c].lo = (xa0 + xa1) * rcp2(pa) + cx[c].lo; cx[c].hi = (xb0 + xb1) * rcp2(pb) + cx[c].hi;
+          }
         } else if (rb.on(r)) {
           f32x4 v0[NCH];
           rb.get(r, v0);
 #pragma unroll
-          for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float x0 = gnew * v0[c][t] + vb[c][t];
-              cl[c][t] += fast_log2(x0);
-              cx[c][t] += fast_rcp(x0);
-            }
+          for (int c = 0; c < NCH; ++c) {
+            const f32x2 xa = gw2 * v0[c].lo + vb[c].lo, xb = gw2 * v0[c].hi + vb[c].hi;
+            cl[c].lo += log2_2(xa); cl[c].hi += log2_2(xb);
+            cx[c].lo += rcp2(xa); cx[c].hi += rcp2(xb);
+          }
         }
       }
       const float xm = rb.xmask(fc), x0 = gnew * rb.xr + vbx;
@@ -694,14 +723,13 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void 
           f32x4 v[NCH];
           rb.get(r, v);
 #pragma unroll
-          for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float sc = gn * v[c][t];
-              const float q = fast_rcp(sc + vb[c][t]);
-              ws[c][t] += sc * q;                 // g Vs / Vx
-              wn[c][t] += vb[c][t] * q;           // Vb / Vx
-            }
+          for (int c = 0; c < NCH; ++c) {
+            const f32x2 g2 = {gn, gn};
+            const f32x2 s0 = g2 * v[c].lo, s1 = g2 * v[c].hi;
+            const f32x2 q0 = rcp2(s0 + vb[c].lo), q1 = rcp2(s1 + vb[c].hi);
+            ws[c].lo = s0 * q0 + ws[c].lo; ws[c].hi = s1 * q1 + ws[c].hi;                         // g Vs / Vx
+            wn[c].lo = vb[c].lo * q0 + wn[c].lo; wn[c].hi = vb[c].hi * q1 + wn[c].hi;             // Vb / Vx
+          }
         }
       const float sc = gn * rb.xr, q = fast_rcp(sc + vbx) * rb.xmask(fc);
       wsx += wave_sum(sc * q);
@@ -799,13 +827,12 @@ __global__ __launch_bounds__(256, 2) void wstats_stream2_kernel(const StreamArgs
         f32x4 v[NCH];
         rb.get(r, v);
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const float q = fast_rcp(s.g * v[c][t] + vb[c][t]);
-            a1[c][t] += q;
-            a2[c][t] += q * q;
-          }
+        for (int c = 0; c < NCH; ++c) {
+          const f32x2 g2 = {s.g, s.g};
+          const f32x2 q0 = rcp2(g2 * v[c].lo + vb[c].lo), q1 = rcp2(g2 * v[c].hi + vb[c].hi);
+          a1[c].lo += q0; a1[c].hi += q1;
+          a2[c].lo = q0 * q0 + a2[c].lo; a2[c].hi = q1 * q1 + a2[c].hi;
+        }
       }
     }
     const float q = fast_rcp(s.g * rb.xr + vbx) * rb.xmask(fc);
@@ -886,13 +913,12 @@ __global__ __launch_bounds__(256, 2) void hg_stream2_kernel(const StreamArgs a) 
           f32x4 v[NCH];
           rb.get(r, v);
 #pragma unroll
-          for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
-              a1[c][t] += q;
-              a2[c][t] += q * q;
-            }
+          for (int c = 0; c < NCH; ++c) {
+            const f32x2 g2 = {gn, gn};
+            const f32x2 q0 = rcp2(g2 * v[c].lo + vb[c].lo), q1 = rcp2(g2 * v[c].hi + vb[c].hi);
+            a1[c].lo += q0; a1[c].hi += q1;
+            a2[c].lo = q0 * q0 + a2[c].lo; a2[c].hi = q1 * q1 + a2[c].hi;
+          }
         }
       }
       const float qx = fast_rcp(gn * rb.xr + vbx) * rb.xmask(fc);

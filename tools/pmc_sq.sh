@@ -5,9 +5,9 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmcsq
 rm -rf $OUT; mkdir -p $OUT
 ARGS="bench.py --steps 1 --warmup 0 --niter 6 --no-cpu-baseline --no-parity-mode --precision ${1:-bf16}"
-rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/a -- python $ARGS > $OUT/a.log 2>&1 &&
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM --output-format csv -d $OUT/b -- python $ARGS > $OUT/b.log 2>&1 &&
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/c -- python $ARGS > $OUT/c.log 2>&1 &&
+timeout -k 10 240 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/a -- python $ARGS > $OUT/a.log 2>&1 &&
+timeout -k 10 240 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM --output-format csv -d $OUT/b -- python $ARGS > $OUT/b.log 2>&1 &&
+timeout -k 10 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/c -- python $ARGS > $OUT/c.log 2>&1 &&
 python - <<'PY'
 import csv, glob, collections
 short = lambda k: k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
