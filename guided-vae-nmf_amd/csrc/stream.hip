@@ -25,7 +25,8 @@
 #define VN_ROWCHUNK 1      // rows per uniform branch in RowBatch::for_rows (2, 3, 5 rows per branch spill more at the 128-register cap: 87 / 106 / 275 scratch operations against 50)
 #endif
 #ifndef VN_HG_EXACT
-#define VN_HG_EXACT 0     // exact-sample-count instantiations of hg_stream: measured slower (the branch-free row loops spill at the 128-register cap: 0.32 vs 0.24 ms)
+#define VN_HG_EXACT 1     // exact-sample-count instantiations of hg_stream (R = 30 / 10, one chunk, rank <= 8): no per-row branches, rows consumed
+                          // as they arrive (precise vmcnt counts): 0.198 -> 0.172 ms.  (Slower while the extra-bin addresses still spilled.)
 #endif
 #ifndef VN_HG_STAGGER
 #define VN_HG_STAGGER 0     // s_sleep(127) units (8128 cycles each) per hardware wave slot at the start of hg_stream
@@ -85,6 +86,7 @@ struct FrameCtx {
   // addresses, loop-invariant, were spilled and every reload (scratch: a memory round trip, waited for with vmcnt(0))
   // stalled the wavefront -- ~25 serial round trips per frame, more than the frame's arithmetic
   float wx;
+  float nw;                    // normW[utt][k] in lane k (hg_stream), same refresh
   int wutt, blk_utt, xutt;
   bool in_lds;                 // wave-uniform: this frame's W rows are the ones in LDS
   __device__ FrameCtx(const StreamArgs& a_, float* wl_) : a(a_), wl(wl_) {
@@ -96,7 +98,11 @@ struct FrameCtx {
     blk_utt = -1;
     xutt = -1;
     wx = 0.f;
+    nw = 1.f;
     in_lds = false;
+  }
+  __device__ __forceinline__ float nwk(int k) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nw), k));
   }
   __device__ __forceinline__ float wxk(int k) const {       // W[utt][F-1][k], wave-uniform (k: compile time)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wx), k));
@@ -113,10 +119,14 @@ struct FrameCtx {
     }
     __syncthreads();
   }
-  __device__ __forceinline__ void set_utt(int utt) {        // wave-uniform
+  __device__ __forceinline__ void set_utt(int utt, const float* normW = nullptr) {        // wave-uniform
     if (utt != xutt) {
       xutt = utt;
       wx = (has_x && lane < KP) ? a.W[((size_t)utt * a.Fs + a.F - 1) * KP + lane] : 0.f;
+      if (normW) nw = lane < KP ? normW[(size_t)utt * KP + lane] : 1.f;
+      // retired inside the branch: merged with the other path as "maybe pending", their first use -- behind the row
+      // loads -- would be waited for with vmcnt(0), i.e. together with every row
+      __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
     }
     if (!WPRIV) { in_lds = utt == blk_utt; return; }
     in_lds = true;
@@ -262,7 +272,8 @@ struct RowBatch {
   __device__ __forceinline__ bool on(int r) const { return RT > 0 ? r < RT : r < nr; }
   using raw_t = typename std::conditional<sizeof(ST) == 4, f32x4, bf16x4>::type;
   raw_t raw[RB][NCH];
-  float xr;                    // lane j: extra bin (F-1) of row j of the batch
+  unsigned xbits;              // lane j: extra bin (F-1) of row j of the batch, as loaded (bf16 bits in the low half / float bits);
+                               // x() converts at the use, so no load site waits for it before issuing the row loads
   int nr;
   // rows r0 .. r0+nr-1 of the frame whose store block starts at `base`; scol = the frame's column of the
   // sample-major slot map (stride NT)
@@ -276,10 +287,12 @@ struct RowBatch {
   template <typename FC>
   __device__ __forceinline__ void load_rows(const FC& fc, const ST* base, int sl, int r0, int R) {
     nr = RT > 0 ? RT : (R - r0 < RB ? R - r0 : RB);
-    xr = fc.has_x ? (float)base[(size_t)sl * fc.a.Fs + fc.a.F - 1] : 0.f;
+    // (row 0 exists in every batch and is loaded without a check: its readlane of `sl` puts the wait for the slot
+    // load on the straight path -- behind a branch, the compiler waits with vmcnt(0) in EVERY row's block, i.e. for
+    // the row load issued just before it, and the batch becomes thirty serial round trips)
 #pragma unroll
     for (int r = 0; r < RB; ++r)
-      if (on(r)) {
+      if (r == 0 || on(r)) {
 #if VN_HG_PROBE == 2
         const ST* row = reinterpret_cast<const ST*>(fc.a.VsS) + (size_t)(__builtin_amdgcn_readlane(sl, r) & 1) * fc.a.Fs;
 #else
@@ -288,6 +301,11 @@ struct RowBatch {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) raw[r][c] = *reinterpret_cast<const raw_t*>(row + (fc.cv[c] ? fc.f0[c] : 0));
       }
+    // extra bin, raw bits (x() converts at the use: a conversion here would wait for every load above)
+    if (fc.has_x) {
+      if constexpr (sizeof(ST) == 2) xbits = reinterpret_cast<const unsigned short*>(base)[(size_t)sl * fc.a.Fs + fc.a.F - 1];
+      else xbits = reinterpret_cast<const unsigned*>(base)[(size_t)sl * fc.a.Fs + fc.a.F - 1];
+    } else xbits = 0u;
   }
   template <typename FC>
   __device__ __forceinline__ void load(const FC& fc, const ST* base, const int32_t* scol, int r0, int R) {
@@ -300,16 +318,16 @@ struct RowBatch {
   __device__ __forceinline__ void load_rows_buf(const FC& fc, __amdgpu_buffer_rsrc_t rs, unsigned frame_off, int sl, int R, int r0 = 0) {
     nr = RT > 0 ? RT : (R - r0 < RB ? R - r0 : RB);
     const unsigned rowb = (unsigned)fc.a.Fs * (unsigned)sizeof(ST);
-    // (raw bits: the conversion would wait for this load before the row loads below are even issued; finish_x()
+    // (raw bits: the conversion would wait for this load before the row loads below are even issued; x()
     // converts at the first use, a frame later)
     if (fc.has_x) {
       const unsigned o = frame_off + (unsigned)sl * rowb + (unsigned)(fc.a.F - 1) * (unsigned)sizeof(ST);
-      if constexpr (sizeof(ST) == 2) xr = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, o, 0, 0));
-      else xr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0));
-    } else xr = 0.f;
+      if constexpr (sizeof(ST) == 2) xbits = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, o, 0, 0);
+      else xbits = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0);
+    } else xbits = 0u;
 #pragma unroll
     for (int r = 0; r < RB; ++r)
-      if (on(r)) {
+      if (r == 0 || on(r)) {
         const unsigned so = frame_off + (unsigned)__builtin_amdgcn_readlane(sl, r) * rowb;       // uniform
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -337,8 +355,9 @@ struct RowBatch {
       }
     }
   }
-  __device__ __forceinline__ void finish_x() {        // after load_rows_buf: extra-bin bits -> float
-    if constexpr (sizeof(ST) == 2) xr = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, xr) << 16);
+  __device__ __forceinline__ float x() const {
+    if constexpr (sizeof(ST) == 2) return __builtin_bit_cast(float, xbits << 16);
+    else return __builtin_bit_cast(float, xbits);
   }
   // Between two passes over the same batch: without this the compiler keeps the UNPACKED floats of the first pass
   // alive for the next one (common-subexpression elimination of the bf16 -> float conversions: 120 registers).
@@ -363,7 +382,8 @@ __device__ __forceinline__ void wave_frames(int NT, int& n_beg, int& n_end) {
   const int wpb = blockDim.x >> 6;
   const int gw = blockIdx.x * wpb + (threadIdx.x >> 6), nw = gridDim.x * wpb;
   const int per = (NT + nw - 1) / nw;
-  n_beg = gw * per;
+  // (wave-uniform by construction; said so, the frame loop and every per-frame address run on the scalar unit)
+  n_beg = __builtin_amdgcn_readfirstlane(gw * per);
   n_end = n_beg + per < NT ? n_beg + per : NT;
 }
 
@@ -385,7 +405,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void 
     const int R0 = a.R < HB ? a.R : HB;              // rows of the first half
     if (n_beg < n_end) {
       h0.load(fc, base_of(n_beg), a.src + n_beg, 0, R0);
-      if (a.R > HB) h1.load(fc, base_of(n_beg), a.src + n_beg, HB, a.R); else h1.nr = 0, h1.xr = 0.f;
+      if (a.R > HB) h1.load(fc, base_of(n_beg), a.src + n_beg, HB, a.R); else h1.nr = 0, h1.xbits = 0u;
     }
     for (int n = n_beg; n < n_end; ++n) {
       const int utt = a.frame_utt[n];
@@ -418,7 +438,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void 
               a2[c].lo = q0 * q0 + a2[c].lo; a2[c].hi = q1 * q1 + a2[c].hi;
             }
           }
-        const float q = fast_rcp(gn * hb.xr + vbx) * hb.xmask(fc);
+        const float q = fast_rcp(gn * hb.x() + vbx) * hb.xmask(fc);
         a1x += wave_sum(q);
         a2x += wave_sum(q * q);
       };
@@ -473,7 +493,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void 
             a2[c].lo = q0 * q0 + a2[c].lo; a2[c].hi = q1 * q1 + a2[c].hi;
           }
         }
-      const float q = fast_rcp(gn * rb.xr + vbx) * rb.xmask(fc);
+      const float q = fast_rcp(gn * rb.x() + vbx) * rb.xmask(fc);
       a1x += wave_sum(q);
       a2x += wave_sum(q * q);
     }
@@ -509,26 +529,33 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
     const ST* base = reinterpret_cast<const ST*>(a.VsS) + (size_t)n * a.Rs * a.Fs;
     const int32_t* srow = a.src + n;
     RBt rb;
-    rb.load(fc, base, srow, 0, a.R);
+    // Order of the frame's requests (vmcnt counts in order, and behind the per-row branches the compiler can only wait
+    // with vmcnt(0)): first every small operand of the frame and the slot map, one round trip together; then, with
+    // nothing else outstanding, the rows; nothing is requested behind the rows until they are consumed.
     const int utt = a.frame_utt[n];
-    fc.set_utt(utt);
     const float gn = a.g[n];
+    const int sl = RBt::load_slots(fc, srow, 0, a.R);
     const f32x2 gn2 = {gn, gn};
     f32x4 vb[NCH], x2[NCH];
     float vbx, x2x;
     fc.load_x2(n, x2, x2x);
+    float hs[KP];
     if (a.gains_only) {
       fc.ext_var(n, vb, vbx);
     } else {
-      // ---- H update (mcem.py:118-121): W already updated and normalised; H carries the pending column norms
-      float hs[KP];
 #pragma unroll
       for (int k = 0; k < KP; k += 4) {
         const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
-        const f32x4 nv = *reinterpret_cast<const f32x4*>(a.normW + (size_t)utt * KP + k);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) hs[k + t] = hv[t] * nv[t];
+        for (int t = 0; t < 4; ++t) hs[k + t] = hv[t];
       }
+    }
+    fc.set_utt(utt, a.gains_only ? nullptr : a.normW);
+    rb.load_rows(fc, base, sl, 0, a.R);
+    if (!a.gains_only) {
+      // ---- H update (mcem.py:118-121): W already updated and normalised; H carries the pending column norms
+#pragma unroll
+      for (int k = 0; k < KP; ++k) hs[k] *= fc.nwk(k);
       fc.noise_var(utt, hs, vb, vbx);
       f32x4 a1[NCH], a2[NCH];
       float a1x = 0.f, a2x = 0.f;
@@ -554,7 +581,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
           }
         };
         rb.for_rows(row1);
-        const float q = fast_rcp(gn * rb.xr + vbx) * rb.xmask(fc);
+        const float q = fast_rcp(gn * rb.x() + vbx) * rb.xmask(fc);
         a1x += wave_sum(q);
         a2x += wave_sum(q * q);
       }
@@ -611,7 +638,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
           }
         };
         rb.for_rows(row2);
-        const float q = fast_rcp(gn * rb.xr + vbx), vq = rb.xr * q * rb.xmask(fc);
+        const float q = fast_rcp(gn * rb.x() + vbx), vq = rb.x() * q * rb.xmask(fc);
         dgx += wave_sum(vq);
         ngx += wave_sum(vq * q);
       }
@@ -663,7 +690,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
           }
         }
       }
-      const float xm = rb.xmask(fc), x0 = gnew * rb.xr + vbx;
+      const float xm = rb.xmask(fc), x0 = gnew * rb.x() + vbx;
       clx += wave_sum(fast_log2(x0) * xm);
       cxx += wave_sum(fast_rcp(x0) * xm);
     }
@@ -731,7 +758,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void 
             wn[c].lo = vb[c].lo * q0 + wn[c].lo; wn[c].hi = vb[c].hi * q1 + wn[c].hi;             // Vb / Vx
           }
         }
-      const float sc = gn * rb.xr, q = fast_rcp(sc + vbx) * rb.xmask(fc);
+      const float sc = gn * rb.x(), q = fast_rcp(sc + vbx) * rb.xmask(fc);
       wsx += wave_sum(sc * q);
       wnx += wave_sum(vbx * q);
     }
@@ -813,7 +840,6 @@ __global__ __launch_bounds__(256, 2) void wstats_stream2_kernel(const StreamArgs
     rb.load_rows_buf(fc, vrs, (unsigned)n * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST), sl, a.R);
   };
   auto compute = [&](int n, RBt& rb, const FS& s) {
-    rb.finish_x();
     fc.set_utt(s.utt);
     f32x4 vb[NCH], a1[NCH], a2[NCH];
     float vbx, a1x = 0.f, a2x = 0.f;
@@ -835,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void wstats_stream2_kernel(const StreamArgs
         }
       }
     }
-    const float q = fast_rcp(s.g * rb.xr + vbx) * rb.xmask(fc);
+    const float q = fast_rcp(s.g * rb.x() + vbx) * rb.xmask(fc);
     a1x = wave_sum(q);
     a2x = wave_sum(q * q);
 #pragma unroll
@@ -891,7 +917,6 @@ __global__ __launch_bounds__(256, 2) void hg_stream2_kernel(const StreamArgs a) 
     rb.load_rows_buf(fc, vrs, (unsigned)n * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST), sl, a.R);
   };
   auto compute = [&](int n, RBt& rb, FS& s) {
-    rb.finish_x();
     s.finish(!a.gains_only);                    // H carries the pending column norms of W
     const int utt = s.utt;
     const float gn = s.g;
@@ -921,7 +946,7 @@ __global__ __launch_bounds__(256, 2) void hg_stream2_kernel(const StreamArgs a) 
           }
         }
       }
-      const float qx = fast_rcp(gn * rb.xr + vbx) * rb.xmask(fc);
+      const float qx = fast_rcp(gn * rb.x() + vbx) * rb.xmask(fc);
       float a1x = wave_sum(qx), a2x = wave_sum(qx * qx);
 #pragma unroll
       for (int c = 0; c < NCH; ++c)
@@ -973,7 +998,7 @@ __global__ __launch_bounds__(256, 2) void hg_stream2_kernel(const StreamArgs a) 
             }
         }
       }
-      const float q = fast_rcp(gn * rb.xr + vbx), vq = rb.xr * q * rb.xmask(fc);
+      const float q = fast_rcp(gn * rb.x() + vbx), vq = rb.x() * q * rb.xmask(fc);
       const float dgx = wave_sum(vq), ngx = wave_sum(vq * q);
 #pragma unroll
       for (int c = 0; c < NCH; ++c)
@@ -1020,7 +1045,7 @@ __global__ __launch_bounds__(256, 2) void hg_stream2_kernel(const StreamArgs a) 
           }
       }
     }
-    const float xm = rb.xmask(fc), x0 = gnew * rb.xr + vbx;
+    const float xm = rb.xmask(fc), x0 = gnew * rb.x() + vbx;
     const float clx = wave_sum(fast_log2(x0) * xm), cxx = wave_sum(fast_rcp(x0) * xm);
     float cs = 0.f;
 #pragma unroll
