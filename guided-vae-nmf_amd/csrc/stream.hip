@@ -24,6 +24,12 @@
 #ifndef VN_ROWCHUNK
 #define VN_ROWCHUNK 1      // rows per uniform branch in RowBatch::for_rows (2, 3, 5 rows per branch spill more at the 128-register cap: 87 / 106 / 275 scratch operations against 50)
 #endif
+#ifndef VN_ROT
+#define VN_ROT 1          // rotating-register W-statistics / H,g kernels for the bench shapes (dev builds: 0 = the batch forms)
+#endif
+#ifndef VN_WS_EXACT
+#define VN_WS_EXACT 0     // exact-sample-count instantiations of wstats_stream2 (R = 30 / 10)
+#endif
 #ifndef VN_HG_EXACT
 #define VN_HG_EXACT 1     // exact-sample-count instantiations of hg_stream (R = 30 / 10, one chunk, rank <= 8): no per-row branches, rows consumed
                           // as they arrive (precise vmcnt counts): 0.198 -> 0.172 ms.  (Slower while the extra-bin addresses still spilled.)
@@ -41,7 +47,7 @@
 #define VN_ROWGRP 6     // rows whose arithmetic the scheduler may interleave in the exact-count stream kernels
 #endif
 #ifndef VN_STREAM2
-#define VN_STREAM2 1      // frame-pipelined W-statistics / H,g kernels (dev builds: 0 = the batch-at-a-time forms)
+#define VN_STREAM2 1      // frame-pipelined W-statistics kernel (dev builds: 0 = the batch-at-a-time form)
 #endif
 
 int vn_ensure_dyn_lds(const void* fn, int bytes);     // plan.hip
@@ -532,10 +538,10 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
     // Order of the frame's requests (vmcnt counts in order, and behind the per-row branches the compiler can only wait
     // with vmcnt(0)): first every small operand of the frame and the slot map, one round trip together; then, with
     // nothing else outstanding, the rows; nothing is requested behind the rows until they are consumed.
+    // (Requesting the operands a frame ahead, so that the rows go out at once, was measured: 0.179 against 0.172 ms.)
     const int utt = a.frame_utt[n];
     const float gn = a.g[n];
     const int sl = RBt::load_slots(fc, srow, 0, a.R);
-    const f32x2 gn2 = {gn, gn};
     f32x4 vb[NCH], x2[NCH];
     float vbx, x2x;
     fc.load_x2(n, x2, x2x);
@@ -552,6 +558,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
     }
     fc.set_utt(utt, a.gains_only ? nullptr : a.normW);
     rb.load_rows(fc, base, sl, 0, a.R);
+    const f32x2 gn2 = {gn, gn};
     if (!a.gains_only) {
       // ---- H update (mcem.py:118-121): W already updated and normalised; H carries the pending column norms
 #pragma unroll
@@ -803,14 +810,12 @@ template <int NCH, int KP>
 struct FrameSmall {            // the per-frame operands besides the rows, requested one frame ahead like the rows
   f32x4 x2[NCH];
   float x2x, g;
-  float h[KP];               // H[:, n] (hg: requested as loaded; times the pending column norms in finish())
-  float nrm[KP];
+  float hl;                  // lane k: H[k, n] (one register instead of KP: two of these structs are live, and a spilled
+                             // member's reload, waited for with vmcnt(0), waits for the whole row prefetch behind it)
   int utt;
-  __device__ __forceinline__ void finish(bool with_norms) {
-    if (with_norms) {
+  __device__ __forceinline__ void get_h(float (&h)[KP]) const {
 #pragma unroll
-      for (int k = 0; k < KP; ++k) h[k] *= nrm[k];
-    }
+    for (int k = 0; k < KP; ++k) h[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hl), k));
   }
 };
 
@@ -830,12 +835,7 @@ __global__ __launch_bounds__(256, 2) void wstats_stream2_kernel(const StreamArgs
   auto request = [&](int n, RBt& rb, FS& s, int sl) {
     s.utt = a.frame_utt[n];
     s.g = a.g[n];
-#pragma unroll
-    for (int k = 0; k < KP; k += 4) {
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) s.h[k + t] = hv[t];
-    }
+    s.hl = a.Ht[(size_t)n * KP + (fc.lane < KP ? fc.lane : 0)];
     fc.load_x2(n, s.x2, s.x2x);
     rb.load_rows_buf(fc, vrs, (unsigned)n * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST), sl, a.R);
   };
@@ -843,7 +843,9 @@ __global__ __launch_bounds__(256, 2) void wstats_stream2_kernel(const StreamArgs
     fc.set_utt(s.utt);
     f32x4 vb[NCH], a1[NCH], a2[NCH];
     float vbx, a1x = 0.f, a2x = 0.f;
-    fc.noise_var(s.utt, s.h, vb, vbx);
+    float h[KP];
+    s.get_h(h);
+    fc.noise_var(s.utt, h, vb, vbx);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) a1[c] = a2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -888,192 +890,166 @@ __global__ __launch_bounds__(256, 2) void wstats_stream2_kernel(const StreamArgs
   }
 }
 
-template <int NCH, int KP, typename ST, int RT>
-__global__ __launch_bounds__(256, 2) void hg_stream2_kernel(const StreamArgs a) {
+
+// ============================================================================
+// Rotating-register forms (bf16 rows, one 256-bin chunk, rank <= 8, exactly RT samples per frame): the bench shapes.
+// A wavefront keeps ONE frame's rows in registers (2 per row) and refills each row's registers with the same row of
+// the NEXT frame right after its last use, so RT row loads stay in flight per wavefront all the time and the loop is
+// straight-line: the compiler's vmcnt counts are exact (wait for the oldest row only), which no form with per-row
+// branches or with a second batch of registers achieved (conservative vmcnt(0) there waits for the whole prefetch;
+// spilled operands, reloaded through vmcnt as well, do the same).  Small per-frame operands are requested a frame ahead,
+// the slot map two frames ahead.
+// ============================================================================
+template <int KP>
+struct RotSmall {              // a frame's operands besides the rows
+  f32x4 x2;
+  // ONE load with per-lane addresses: lane k < KP: H[k, n]; lane KP: the frame's utterance (int bits); lane KP+1: g[n];
+  // lane KP+2: X2 of the extra bin.  Read back with readlane at the first use, two frames later -- a scalar taken at the
+  // load (the compiler moves a uniform value to an SGPR at once) would wait there, for every older row load as well.
+  float pk;
+  __device__ __forceinline__ float lane_f(int l) const { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), l)); }
+  __device__ __forceinline__ int utt() const { return __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), KP); }
+  __device__ __forceinline__ float g() const { return lane_f(KP + 1); }
+  __device__ __forceinline__ float x2x() const { return lane_f(KP + 2); }
+};
+
+template <int KP, int RT>
+struct RotCtx {
+  using FC = FrameCtx<1, KP, __bf16>;
+  const StreamArgs& a;
+  const FC& fc;
+  __amdgpu_buffer_rsrc_t vrs;
+  unsigned rowb, frameb, voff, xvoff;
+  const char* pk_base;         // per-lane base and stride (bytes per frame) of the packed small-operand load
+  unsigned pk_stride;
+  // two register sets: the frame in set S is consumed while set 1-S is refilled with the next frame's rows, row by
+  // row behind the uses.  (One set refilled in place would do -- a row's registers are free after its last use -- but
+  // the register allocator does not coalesce the loop-carried values and copies every row at the back edge, which
+  // waits for the whole prefetch.)
+  bf16x4 raw[2][RT];
+  unsigned xb[2];              // lane j < RT: bf16 bits of the extra bin of row j
+  __device__ RotCtx(const StreamArgs& a_, const FC& fc_) : a(a_), fc(fc_) {
+    vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.VsS), 0, (int)((unsigned)a.NT * (unsigned)(a.Rs * a.Fs) * 2u), 0x00020000);
+    rowb = (unsigned)a.Fs * 2u;
+    frameb = (unsigned)a.Rs * rowb;
+    voff = (unsigned)(fc.cv[0] ? fc.f0[0] : 0) * 2u;
+    xvoff = (unsigned)(a.F - 1) * 2u;
+    xb[0] = xb[1] = 0u;
+    const int l = fc.lane;
+    if (l == KP) { pk_base = reinterpret_cast<const char*>(a.frame_utt); pk_stride = 4u; }
+    else if (l == KP + 1) { pk_base = reinterpret_cast<const char*>(a.g); pk_stride = 4u; }
+    else if (l == KP + 2 && fc.has_x) { pk_base = reinterpret_cast<const char*>(a.X2 + a.F - 1); pk_stride = (unsigned)a.Fs * 4u; }
+    else if (a.Ht) { pk_base = reinterpret_cast<const char*>(a.Ht + (l < KP ? l : 0)); pk_stride = (unsigned)KP * 4u; }
+    else { pk_base = reinterpret_cast<const char*>(a.g); pk_stride = 4u; }
+  }
+  __device__ __forceinline__ int slots(int n) const {       // lane j: slot of row j of frame n (sample-major map)
+    return a.src[(size_t)(fc.lane < RT ? fc.lane : 0) * a.NT + n];
+  }
+  __device__ __forceinline__ void req_small(int n, RotSmall<KP>& s) const {
+    s.pk = *reinterpret_cast<const float*>(pk_base + (size_t)n * pk_stride);
+    f32x4 x2v[1];
+    float unused;
+    fc.load_x2(n, x2v, unused);
+    s.x2 = x2v[0];
+  }
+  // Row r of frame n into set S.  `after`: a value the last use of the registers' previous content produces -- the
+  // load's address is made to depend on it, or the compiler hoists all RT refills above the frame's arithmetic.
+  // vbase: voff, or an offset past the buffer (the hardware returns zeros without touching memory: no frame follows)
+  template <int S>
+  __device__ __forceinline__ void req_row(int n, int sl, int r, float after, unsigned vbase) {
+    const unsigned so = (unsigned)n * frameb + (unsigned)__builtin_amdgcn_readlane(sl, r) * rowb;
+    unsigned vo = vbase;
+    asm volatile("" : "+v"(vo) : "v"(after));
+    raw[S][r] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(vrs, vo, so, 0));
+  }
+  template <int S>
+  __device__ __forceinline__ void req_x(int n, int sl, bool on) {
+    if (fc.has_x) xb[S] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(vrs, on ? (unsigned)sl * rowb + xvoff : 0xF0000000u, (unsigned)n * frameb, 0);
+  }
+  template <int S>
+  __device__ __forceinline__ f32x4 row(int r) const {
+    return f32x4{(float)raw[S][r][0], (float)raw[S][r][1], (float)raw[S][r][2], (float)raw[S][r][3]};
+  }
+  template <int S>
+  __device__ __forceinline__ float x() const { return __builtin_bit_cast(float, xb[S] << 16); }
+  __device__ __forceinline__ float xmask() const { return (fc.has_x && fc.lane < RT) ? 1.f : 0.f; }
+};
+
+template <int KP>
+__device__ __forceinline__ void rot_h(float hl, float (&h)[KP]) {
+#pragma unroll
+  for (int k = 0; k < KP; ++k) h[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hl), k));
+}
+
+template <int KP, int RT>
+__global__ __launch_bounds__(256, 2) void wstats_rot_kernel(const StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
-  FrameCtx<NCH, KP, ST> fc(a, wlds + (KP <= 8 ? (size_t)(threadIdx.x >> 6) * a.Fs * KP : 0));
-  fc.stage_block_w();
-  using RBt = RowBatch<NCH, ST, 1, RT>;
-  using FS = FrameSmall<NCH, KP>;
+  FrameCtx<1, KP, __bf16> fc(a, wlds + (size_t)(threadIdx.x >> 6) * a.Fs * KP);
   int n_beg, n_end;
   wave_frames(a.NT, n_beg, n_end);
   if (n_beg >= n_end) return;
-  __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.VsS), 0, (int)((unsigned)a.NT * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST)), 0x00020000);
-  // slots are requested TWO frames ahead, rows and operands one frame ahead: the row addresses depend on the slots,
-  // and a wait for the slots placed between two frames' row loads would expose a full memory round trip per frame
-  auto request = [&](int n, RBt& rb, FS& s, int sl) {
-    s.utt = a.frame_utt[n];
-    s.g = a.g[n];
-    if (!a.gains_only) {
+  RotCtx<KP, RT> rc(a, fc);
+  // Small operands TWO frames ahead (cur, nx1, nx2), like the slot map: requested a single frame ahead they are younger
+  // than the previous step's refills, and the wait for them (vmcnt counts in order) at the top of a step would be a wait
+  // for every row of the frame -- the rows refilled last would get no time at all.
+  RotSmall<KP> cur, nx1, nx2;
+  int sl[2];                   // sl[S]: slots of the frame that goes into set S next
+  const int n_last = n_end - 1;
+  auto clampf = [&](int n) { return n < n_last ? n : n_last; };
+  {
+    sl[0] = rc.slots(n_beg);
+    rc.req_small(n_beg, cur);
+    rc.req_small(clampf(n_beg + 1), nx1);
+    sl[1] = rc.slots(clampf(n_beg + 1));
 #pragma unroll
-      for (int k = 0; k < KP; k += 4) {
-        const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
-        const f32x4 nv = *reinterpret_cast<const f32x4*>(a.normW + (size_t)s.utt * KP + k);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { s.h[k + t] = hv[t]; s.nrm[k + t] = nv[t]; }      // (multiplied in compute: no wait here)
-      }
-    }
-    fc.load_x2(n, s.x2, s.x2x);
-    rb.load_rows_buf(fc, vrs, (unsigned)n * (unsigned)(a.Rs * a.Fs) * (unsigned)sizeof(ST), sl, a.R);
-  };
-  auto compute = [&](int n, RBt& rb, FS& s) {
-    s.finish(!a.gains_only);                    // H carries the pending column norms of W
-    const int utt = s.utt;
-    const float gn = s.g;
-    f32x4 vb[NCH];
-    float vbx;
-    if (a.gains_only) {
-      fc.ext_var(n, vb, vbx);
-    } else {
-      // ---- H update (mcem.py:118-121): W already updated and normalised
-      fc.set_utt(utt);
-      fc.noise_var(utt, s.h, vb, vbx);
-      f32x4 a1[NCH], a2[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) a1[c] = a2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < RBt::RB; ++r) {
-        if (RT > 0 && (r % VN_ROWGRP) == 0) __builtin_amdgcn_sched_barrier(0);
-        if (rb.on(r)) {
-          f32x4 v[NCH];
-          rb.get(r, v);
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            const f32x2 g2 = {gn, gn};
-            const f32x2 q0 = rcp2(g2 * v[c].lo + vb[c].lo), q1 = rcp2(g2 * v[c].hi + vb[c].hi);
-            a1[c].lo += q0; a1[c].hi += q1;
-            a2[c].lo = q0 * q0 + a2[c].lo; a2[c].hi = q1 * q1 + a2[c].hi;
-          }
-        }
-      }
-      const float qx = fast_rcp(gn * rb.x() + vbx) * rb.xmask(fc);
-      float a1x = wave_sum(qx), a2x = wave_sum(qx * qx);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          a2[c][t] = fc.cv[c] ? a2[c][t] * s.x2[c][t] : 0.f;
-          a1[c][t] = fc.cv[c] ? a1[c][t] : 0.f;
-        }
-      const bool lead = fc.lane == 0 && fc.has_x;
-      a2x = lead ? a2x * s.x2x : 0.f;
-      a1x = lead ? a1x : 0.f;
-      float hn[KP];
-#pragma unroll
-      for (int k = 0; k < KP; ++k) {
-        float nu, de;
-        fc.w_dot(utt, k, a2, a1, a2x, a1x, nu, de);
-        nu = wave_sum(nu);
-        de = wave_sum(de);
-        hn[k] = k < a.K ? s.h[k] * __builtin_amdgcn_sqrtf(nu * fast_rcp(de)) : 0.f;        // mcem.py:121
-      }
-      if (fc.lane == 0) {
-#pragma unroll
-        for (int k = 0; k < KP; k += 4)
-          *reinterpret_cast<f32x4*>(a.Ht + (size_t)n * KP + k) = f32x4{hn[k], hn[k + 1], hn[k + 2], hn[k + 3]};
-      }
-      fc.noise_var(utt, hn, vb, vbx);                                                      // mcem.py:124-125
-    }
-    // ---- g update (mcem.py:138-142 / :564-568)
-    float nu = 0.f, de = 0.f;
-    rb.repack();
-    {
-      f32x4 ng[NCH], dg[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) ng[c] = dg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < RBt::RB; ++r) {
-        if (RT > 0 && (r % VN_ROWGRP) == 0) __builtin_amdgcn_sched_barrier(0);
-        if (rb.on(r)) {
-          f32x4 v[NCH];
-          rb.get(r, v);
-#pragma unroll
-          for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float q = fast_rcp(gn * v[c][t] + vb[c][t]);
-              const float vq = v[c][t] * q;
-              dg[c][t] += vq;                 // sum_r Vs / Vx
-              ng[c][t] += vq * q;             // sum_r Vs / Vx^2
-            }
-        }
-      }
-      const float q = fast_rcp(gn * rb.x() + vbx), vq = rb.x() * q * rb.xmask(fc);
-      const float dgx = wave_sum(vq), ngx = wave_sum(vq * q);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-        if (fc.cv[c]) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) { nu += s.x2[c][t] * ng[c][t]; de += dg[c][t]; }
-        }
-      if (fc.lane == 0 && fc.has_x) { nu += s.x2x * ngx; de += dgx; }
-      nu = wave_sum(nu);
-      de = wave_sum(de);
-    }
-    const float gnew = gn * __builtin_amdgcn_sqrtf(nu * fast_rcp(de));                     // mcem.py:142
-    if (fc.lane == 0) a.g[n] = gnew;
-    // ---- cost (mcem.py:70) with the refreshed variances (:151-152); samples two at a time
-    rb.repack();
-    f32x4 cl[NCH], cx[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) cl[c] = cx[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < RBt::RB; r += 2) {
-      if (rb.on(r + 1)) {
-        f32x4 v0[NCH], v1[NCH];
-        rb.get(r, v0);
-        rb.get(r + 1, v1);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const float x0 = gnew * v0[c][t] + vb[c][t], x1 = gnew * v1[c][t] + vb[c][t];
-            const float pp = x0 * x1;
-            cl[c][t] += fast_log2(pp);
-            cx[c][t] += (x0 + x1) * fast_rcp(pp);
-          }
-      } else if (rb.on(r)) {
-        f32x4 v0[NCH];
-        rb.get(r, v0);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const float x0 = gnew * v0[c][t] + vb[c][t];
-            cl[c][t] += fast_log2(x0);
-            cx[c][t] += fast_rcp(x0);
-          }
-      }
-    }
-    const float xm = rb.xmask(fc), x0 = gnew * rb.x() + vbx;
-    const float clx = wave_sum(fast_log2(x0) * xm), cxx = wave_sum(fast_rcp(x0) * xm);
-    float cs = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-      if (fc.cv[c]) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) cs += cl[c][t] * LN2_F + s.x2[c][t] * cx[c][t];
-      }
-    if (fc.lane == 0 && fc.has_x) cs += clx * LN2_F + s.x2x * cxx;
-    const double cd = sum_rows4_d((double)sum_row16(cs));     // rows in fp32 (DPP), then fp64 across the 4 rows
-    if (fc.lane == 0) a.cost_frames[n] = cd;
-  };
-  auto slots = [&](int n) { return n < n_end ? RBt::load_slots(fc, a.src + n, 0, a.R) : 0; };
-  RBt rbA, rbB;
-  FS sA, sB;
-  int sl1 = slots(n_beg + 1);
-  request(n_beg, rbA, sA, slots(n_beg));
-  for (int n = n_beg; n < n_end; n += 2) {
-    int sl2 = 0, sl3 = 0;
-    if (n + 1 < n_end) { request(n + 1, rbB, sB, sl1); sl2 = slots(n + 2); }
-    compute(n, rbA, sA);
-    if (n + 1 < n_end) {
-      if (n + 2 < n_end) { request(n + 2, rbA, sA, sl2); sl3 = slots(n + 3); }
-      compute(n + 1, rbB, sB);
-    }
-    sl1 = sl3;
+    for (int r = 0; r < RT; ++r) rc.template req_row<0>(n_beg, sl[0], r, 0.f, rc.voff);
+    rc.template req_x<0>(n_beg, sl[0], true);
   }
+  // frame n from set S; set 1-S gets frame n+1 (nothing behind the last frame: refills past the buffer's end)
+  auto step = [&](int n, auto set_c) {
+    constexpr int S = decltype(set_c)::value, T = 1 - S;
+    const bool more = n < n_last;
+    const int nn = clampf(n + 1);
+    rc.req_small(clampf(n + 2), nx2);
+    sl[S] = rc.slots(clampf(n + 2));
+    const int utt = cur.utt();
+    const float gn = cur.g();
+    fc.set_utt(utt);
+    float h[KP];
+    rot_h<KP>(cur.pk, h);
+    f32x4 vb[1], a1, a2;
+    float vbx;
+    fc.noise_var(utt, h, vb, vbx);
+    a1 = a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x2 g2 = {gn, gn};
+    const unsigned vnext = more ? rc.voff : 0xF0000000u;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      const f32x4 v = rc.template row<S>(r);
+      const f32x2 q0 = rcp2(g2 * v.lo + vb[0].lo), q1 = rcp2(g2 * v.hi + vb[0].hi);
+      a1.lo += q0; a1.hi += q1;
+      a2.lo = q0 * q0 + a2.lo; a2.hi = q1 * q1 + a2.hi;
+      rc.template req_row<T>(nn, sl[T], r, a2[3], vnext);
+      __builtin_amdgcn_sched_barrier(0);             // one row per region
+    }
+    const float q = fast_rcp(gn * rc.template x<S>() + vbx) * rc.xmask();
+    rc.template req_x<T>(nn, sl[T], more);
+    const float a1x = wave_sum(q), a2x = wave_sum(q * q);
+    a2 *= cur.x2;
+    f32x4 o1[1] = {a1}, o2[1] = {a2};
+    fc.store_row(a.A1 + (size_t)n * a.Fs, o1, a1x);
+    fc.store_row(a.P + (size_t)n * a.Fs, o2, a2x * cur.x2x());
+    cur = nx1;
+    nx1 = nx2;
+  };
+  int n = n_beg;
+  for (; n < n_last; n += 2) {
+    step(n, std::integral_constant<int, 0>{});
+    step(n + 1, std::integral_constant<int, 1>{});
+  }
+  if (n == n_last) step(n, std::integral_constant<int, 0>{});
 }
+
 
 StreamArgs base_args(const vaenmf_plan* p) {
   StreamArgs a = {};
@@ -1096,21 +1072,37 @@ int launch_st(StreamArgs a, int grid, hipStream_t st) {
                    : (KIND == SK_HG ? (const void*)hg_stream_kernel<NCH, KP, ST> : (const void*)wf_stream_kernel<NCH, KP, ST>);
   if (int e = vn_ensure_dyn_lds(fn, 80 * 1024)) return e;
   constexpr bool PIPE_OK = NCH == 1 && KP <= 8;
-  if (PIPE_OK && VN_STREAM2 && (KIND == SK_WSTATS || (KIND == SK_HG && VN_STREAM2 > 1)) && a.R <= RowBatch<NCH, ST>::RB) {
-    // frame-pipelined forms: two resident wavefronts per SIMD, one resident set per launch
+  // (The same form of the H/g kernel needs two register sets of 60 plus the three passes' working set: it spills at 256
+  // registers with 30 samples -- 0.62 ms against 0.17 for the batch form -- and gains nothing with 10; not kept.)
+  if (VN_ROT && PIPE_OK && sizeof(ST) == 2 && KIND == SK_WSTATS && (a.R == 30 || a.R == 10)) {
+    constexpr int K1 = PIPE_OK ? KP : 8;
+    int g4 = a.n_sms * 2;                               // one resident set: 2 workgroups of 4 wavefronts per CU (two per SIMD)
+    if (g4 * 4 > a.NT) g4 = (a.NT + 3) / 4;
+    if (a.R == 30) {
+      if (int e = vn_ensure_dyn_lds((const void*)wstats_rot_kernel<K1, 30>, 80 * 1024)) return e;
+      hipLaunchKernelGGL((wstats_rot_kernel<K1, 30>), dim3(g4), dim3(256), lds, st, a);
+    } else {
+      if (int e = vn_ensure_dyn_lds((const void*)wstats_rot_kernel<K1, 10>, 80 * 1024)) return e;
+      hipLaunchKernelGGL((wstats_rot_kernel<K1, 10>), dim3(g4), dim3(256), lds, st, a);
+    }
+    return 0;
+  }
+  if (PIPE_OK && VN_STREAM2 && KIND == SK_WSTATS && a.R <= RowBatch<NCH, ST>::RB) {
+    // frame-pipelined form: two resident wavefronts per SIMD, one resident set per launch.  (The same form of the H/g
+    // kernel was measured twice, 0.23 ms against 0.17-0.20 for the batch-at-a-time one at four wavefronts per SIMD,
+    // and is not kept; exact-row-count instantiations of this one spill: 0.29 vs 0.155 ms.)
     int g2 = a.n_sms * 2;
     if (g2 * 4 > a.NT) g2 = (a.NT + 3) / 4;
     constexpr int N1 = PIPE_OK ? NCH : 1, K1 = PIPE_OK ? KP : 8;
-#define VN_GO2(RT)                                                                                                                 \
-    do {                                                                                                                               \
-      const void* fn2 = KIND == SK_WSTATS ? (const void*)wstats_stream2_kernel<N1, K1, ST, RT> : (const void*)hg_stream2_kernel<N1, K1, ST, RT>; \
-      if (int e = vn_ensure_dyn_lds(fn2, 80 * 1024)) return e;                                                                         \
-      if (KIND == SK_WSTATS) hipLaunchKernelGGL((wstats_stream2_kernel<N1, K1, ST, RT>), dim3(g2), dim3(256), lds, st, a);             \
-      else hipLaunchKernelGGL((hg_stream2_kernel<N1, K1, ST, RT>), dim3(g2), dim3(256), lds, st, a);                                    \
+#define VN_GO2(RT)                                                                                         \
+    do {                                                                                                       \
+      if (int e = vn_ensure_dyn_lds((const void*)wstats_stream2_kernel<N1, K1, ST, RT>, 80 * 1024)) return e; \
+      hipLaunchKernelGGL((wstats_stream2_kernel<N1, K1, ST, RT>), dim3(g2), dim3(256), lds, st, a);           \
     } while (0)
-    // (exact-row-count instantiations, RT = 30 / 10, were measured: without the per-row branches the compiler
-    // interleaves every row and spills -- W-statistics 0.29 vs 0.155 ms, H/g 0.79 vs 0.29 ms -- so only RT = 0 ships)
-    VN_GO2(0);
+    constexpr int RBm = RowBatch<N1, ST>::RB;
+    if (VN_WS_EXACT && a.R == 30 && RBm >= 30) VN_GO2((RBm >= 30 ? 30 : 0));
+    else if (VN_WS_EXACT && a.R == 10) VN_GO2(10);
+    else VN_GO2(0);
 #undef VN_GO2
     return 0;
   }
