@@ -34,11 +34,17 @@ __device__ long long g_wc_stamp[32];
 #ifndef VN_PF
 #define VN_PF 1
 #endif
+#ifndef VN_PACKED
+#define VN_PACKED 1
+#endif
+#ifndef VN_TPM
+#define VN_TPM 2      // transcendentals scheduled right behind each MFMA (a packed instruction waits for a matrix instruction in flight); 0: mixed with the other VALU work
+#endif
 #ifndef VN_TPR
 #define VN_TPR 1
 #endif
 #ifndef VN_VPER
-#define VN_VPER 6
+#define VN_VPER 8
 #endif
 #ifndef VN_SB
 #define VN_SB __builtin_amdgcn_sched_barrier(0)
@@ -109,11 +115,22 @@ __device__ __forceinline__ void pack4(const f32x4 h, bf16x4& hi, bf16x4& lo) {
     lo[t] = SPLIT ? (__bf16)(h[t] - (float)x) : (__bf16)0.f;
   }
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Two elements per non-transcendental instruction (v_pk_add/mul/fma_f32): next to transcendentals a packed instruction
+// costs the issue slot of a plain one (tools/ubench/overlap.hip: 4.4 against 4.2 ticks, for twice the work).
 __device__ __forceinline__ f32x4 tanh4(const f32x4 a) {
+#if VN_PACKED
+  const f32x2 one = {1.f, 1.f}, m2 = {-2.f, -2.f};
+  const f32x2 d0 = f32x2{fast_exp(a[0]), fast_exp(a[1])} + one, d1 = f32x2{fast_exp(a[2]), fast_exp(a[3])} + one;
+  const f32x2 r0 = {fast_rcp(d0[0]), fast_rcp(d0[1])}, r1 = {fast_rcp(d1[0]), fast_rcp(d1[1])};
+  const f32x2 h0 = m2 * r0 + one, h1 = m2 * r1 + one;
+  return f32x4{h0[0], h0[1], h1[0], h1[1]};
+#else
   f32x4 h;
 #pragma unroll
   for (int t = 0; t < 4; ++t) h[t] = fast_tanh(a[t]);
   return h;
+#endif
 }
 template <bool SPLIT>
 __device__ __forceinline__ f32x4 mma(const bf16x8 whi, const bf16x8 wlo, const bf16x8 ahi, const bf16x8 alo, f32x4 acc) {
@@ -335,7 +352,12 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
 #pragma unroll
             for (int s = 0; s < NKS; ++s) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+#if VN_TPM > 0
+              __builtin_amdgcn_sched_group_barrier(0x400, VN_TPM, 0);     // transcendentals first (see VN_TPM)
+              __builtin_amdgcn_sched_group_barrier(0x002, VN_VPER - VN_TPM, 0);
+#else
               __builtin_amdgcn_sched_group_barrier(0x402, VN_VPER, 0);    // VALU / transcendental
+#endif
             }
           }
           if (VN_TPR <= 1 || (t % VN_TPR) == VN_TPR - 1 || t == N) VN_SB;      // VN_TPR tiles per scheduling region
@@ -388,6 +410,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
       // ---- output layer: each finished tile straight into the energy epilogue
       double e = 0.0;
       float ef = 0.f;
+      f32x2 pl2 = {0.f, 0.f}, px2 = {0.f, 0.f};
+      (void)ef;
       unsigned pk_even0 = 0, pk_even1 = 0;
       run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, MAXT>{},
                 [&](int t, int s, bf16x8& hi, bf16x8& lo) {
@@ -405,6 +429,17 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
                   f32x4 ev;
 #pragma unroll
                   for (int j = 0; j < 4; ++j) ev[j] = fast_exp(acc[j]);
+#if VN_PACKED
+                  {
+                    // pairs (bin 0, bin 2) and (bin 1, bin 3): the two pairs are the two lanes of the packed instructions
+                    const f32x2 g2 = {gn, gn};
+                    const f32x2 v0 = g2 * ev.lo + vb[t].lo, v1 = g2 * ev.hi + vb[t].hi;
+                    const f32x2 pp = v0 * v1;
+                    pl2 += f32x2{fast_log2(pp[0]), fast_log2(pp[1])};
+                    const f32x2 rc = {fast_rcp(pp[0]), fast_rcp(pp[1])};
+                    px2 = (x2[t].lo * v1 + x2[t].hi * v0) * rc + px2;
+                  }
+#else
                   float pl = 0.f, px = 0.f;
 #pragma unroll
                   for (int j = 0; j < 4; j += 2) {
@@ -414,6 +449,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
                     pl += fast_log2(pp);
                     px += (x2[t][j] * v1 + x2[t][j + 1] * v0) * fast_rcp(pp);
                   }
+#endif
                   if (DOST) {
                     if (SPLIT) {
                       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), vrs, voff + 16u * q + 64u * t, 0, 0);
@@ -427,10 +463,21 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
                       }
                     }
                   }
+#if VN_PACKED
+                  if ((t & 1) == 1) {          // fp32 over two tiles, fp64 across them
+                    e += (double)((pl2[0] + pl2[1]) * LN2_F + (px2[0] + px2[1]));
+                    pl2 = px2 = f32x2{0.f, 0.f};
+                  }
+#else
                   ef += pl * LN2_F + px;
                   if ((t & 1) == 1) { e += (double)ef; ef = 0.f; }
+#endif
                 });
+#if VN_PACKED
+      e += (double)((pl2[0] + pl2[1]) * LN2_F + (px2[0] + px2[1]));
+#else
       e += (double)ef;
+#endif
       WC_STAMP(3);
 #ifdef VN_EXP_F32SUM
       return (double)sum_rows4((float)e);
