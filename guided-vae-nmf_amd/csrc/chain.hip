@@ -77,7 +77,7 @@ struct WcArgs {
   const int32_t* frame_off;
   const uint64_t* utt_seed;
   const float *eps, *u;            // replay draws or null
-  int Kp, NT, Rcap, nsamples, burnin, rng_mode, update_Z;
+  int Kp, NT, n_utts, Rcap, nsamples, burnin, rng_mode, update_Z;
   int n_hi_lds;                    // W3 tiles whose hi fragments are in LDS (the rest streams from L2)
   int b1_lds;                      // M2 at 8 wavefronts: byte offset of the per-wave stash of the layer-1 bias rows
   uint32_t call;
@@ -209,6 +209,10 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
   __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(a.src, 0, STORE ? (int)((unsigned)a.NT * (unsigned)a.Rs * 4u) : 0, 0x00020000);
   __amdgpu_buffer_rsrc_t acc_rs = __builtin_amdgcn_make_buffer_rsrc(a.acc_out, 0, a.acc_out ? (int)((unsigned)a.NT * (unsigned)S * 4u) : 0, 0x00020000);
   __amdgpu_buffer_rsrc_t eps_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.eps), 0, a.eps ? (int)((unsigned)a.NT * (unsigned)S * LAT * 4u) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t x2in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X2), 0, (int)((unsigned)a.NT * (unsigned)a.Fs * 4u), 0x00020000);
+  __amdgpu_buffer_rsrc_t vbin_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Vb), 0, a.Vb ? (int)((unsigned)a.NT * (unsigned)a.Fs * 4u) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, a.W ? (int)((unsigned)a.n_utts * (unsigned)a.Fs * (unsigned)a.Kp * 4u) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Ht), 0, a.Ht ? (int)((unsigned)a.NT * (unsigned)a.Kp * 4u) : 0, 0x00020000);
   __amdgpu_buffer_rsrc_t u_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u ? (int)((unsigned)a.NT * (unsigned)S * 4u) : 0, 0x00020000);
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -220,31 +224,38 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
     // ---- per-(bin, frame) constants in accumulator layout: X2 and Vb = W H (mcem.py:81-82) or the given noise PSD.
     // Padding bins: X2 = 0, Vb = 1 and (b3 = -200, W3 = 0) Vs = 0, so their term is exactly 0.
     f32x4 x2[MAXT], vb[MAXT];
+    {
+      // Through buffer resources: a tile's address is the resource (SGPRs) + one per-lane byte offset + a scalar or
+      // immediate tile offset.  With 64-bit pointers the compiler kept an address pair per (tile, bin) alive and spilled
+      // them -- the only scratch of the kernel, and a kernel with scratch pays a scratch-memory set-up per dispatch.
+      const unsigned rowF = (unsigned)nrow * (unsigned)a.Fs;                     // first element of the frame's row
+      const unsigned uF = (unsigned)utt * (unsigned)a.Fs;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-      x2[t] = f32x4{0, 0, 0, 0};
-      vb[t] = f32x4{1, 1, 1, 1};
-      if (tile_on(t)) {
-        const int f0 = bin0(t);
-        f32x4 xv = *reinterpret_cast<const f32x4*>(a.X2 + (size_t)nrow * a.Fs + f0);
-        f32x4 v = {0, 0, 0, 0};
-        if (a.Vb) {
-          v = *reinterpret_cast<const f32x4*>(a.Vb + (size_t)nrow * a.Fs + f0);
-        } else {
-          for (int k = 0; k < a.Kp; k += 4) {              // (once per launch: a plain loop, operands from L1/L2)
-            const f32x4 h4 = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)nrow * a.Kp + k);
+      for (int t = 0; t < MAXT; ++t) {
+        x2[t] = f32x4{0, 0, 0, 0};
+        vb[t] = f32x4{1, 1, 1, 1};
+        if (tile_on(t)) {
+          const int f0 = bin0(t);
+          f32x4 xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x2in_rs, (rowF + (unsigned)f0) * 4u, 0, 0));
+          f32x4 v = {0, 0, 0, 0};
+          if (a.Vb) {
+            v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vbin_rs, (rowF + (unsigned)f0) * 4u, 0, 0));
+          } else {
+            for (int k = 0; k < a.Kp; k += 4) {              // (once per launch: a plain loop, operands from L1/L2)
+              const f32x4 h4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rs, ((unsigned)nrow * (unsigned)a.Kp + (unsigned)k) * 4u, 0, 0));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.W + ((size_t)utt * a.Fs + f0 + j) * a.Kp + k);
-              v[j] += w4[0] * h4[0] + w4[1] * h4[1] + w4[2] * h4[2] + w4[3] * h4[3];
+              for (int j = 0; j < 4; ++j) {
+                const f32x4 w4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, ((uF + (unsigned)(f0 + j)) * (unsigned)a.Kp + (unsigned)k) * 4u, 0, 0));
+                v[j] += w4[0] * h4[0] + w4[1] * h4[1] + w4[2] * h4[2] + w4[3] * h4[3];
+              }
             }
           }
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (f0 + j >= a.F) { xv[j] = 0.f; v[j] = 1.f; }
-        x2[t] = xv;
-        vb[t] = v;
+          for (int j = 0; j < 4; ++j)
+            if (f0 + j >= a.F) { xv[j] = 0.f; v[j] = 1.f; }
+          x2[t] = xv;
+          vb[t] = v;
+        }
       }
     }
     constexpr bool B1L = M2 && NWAVES == 8;                // layer-1 bias rows parked in LDS (see above)
@@ -635,7 +646,7 @@ int vn_launch_wchain(vaenmf_plan* p, const VnChainCall& cc, hipStream_t st) {
   a.VsS = cc.VsS; a.VsS_bytes = (unsigned)cc.VsS_bytes; a.src = cc.src; a.Rs = cc.Rs;
   a.wt_utt = p->d_wt_utt; a.wt_n0 = p->d_wt_n0; a.wt_cnt = p->d_wt_cnt; a.n_wtiles = p->n_wtiles;
   a.frame_off = p->d_frame_off; a.utt_seed = p->d_utt_seed; a.eps = cc.eps; a.u = cc.u;
-  a.Kp = p->Kp; a.NT = p->NT; a.Rcap = cc.Rcap; a.nsamples = cc.nsamples; a.burnin = cc.burnin;
+  a.Kp = p->Kp; a.NT = p->NT; a.n_utts = p->n_utt; a.Rcap = cc.Rcap; a.nsamples = cc.nsamples; a.burnin = cc.burnin;
   a.rng_mode = cc.rng_mode; a.update_Z = cc.update_Z; a.call = cc.call; a.sd = cc.sd;
   a.n_hi_lds = p->NT3c;
   const size_t fixed = split ? WcLds<true>::fixed_bytes : WcLds<false>::fixed_bytes;

@@ -32,7 +32,7 @@ P("# HBM traffic (separate --pmc passes, niter=10): FETCH_SIZE and WRITE_SIZE ar
 P("# MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads on gfx950 -> doubled below")
 fa, fn, _ = pmc("pmc_fetch"); wa, wn, _ = pmc("pmc_write")
 for k in fa:
-    if not any(s in k for s in ("chain_kernel", "decode_kernel", "stream_kernel", "stream2_kernel", "w_update", "w_partial")): continue
+    if not any(s in k for s in ("chain_kernel", "decode_kernel", "stream_kernel", "stream2_kernel", "rot_kernel", "w_update", "w_partial")): continue
     n = len(fn[k]); f = fa[k]["FETCH_SIZE"] / n; w = wa.get(k, {}).get("WRITE_SIZE", 0.0) / max(len(wn.get(k, [1])), 1)
     P("%-92s launches %4d  FETCH_SIZE/launch %10.1f KB (x2 = %8.2f MB)  WRITE_SIZE/launch %10.1f KB  => HBM %8.2f MB/launch"
       % (k, n, f, 2 * f / 1024, w, (2 * f + w) / 1024))
@@ -47,7 +47,7 @@ P("")
 P("# SQ counters (niter=10), summed over launches; *_CYCLES of waves are quad-cycles, VALU_MFMA_BUSY in cycles")
 sa, sn, _ = pmc("pmc_sq")
 for k in sa:
-    if not any(s in k for s in ("chain_kernel", "decode_kernel", "stream_kernel", "stream2_kernel")): continue
+    if not any(s in k for s in ("chain_kernel", "decode_kernel", "stream_kernel", "stream2_kernel", "rot_kernel")): continue
     v = sa[k]; wc = v["SQ_WAVE_CYCLES"]
     P("%-92s launches %d" % (k, len(sn[k])))
     for c in sorted(v): P("    %-28s %16.0f   (%.3f of SQ_WAVE_CYCLES)" % (c, v[c], v[c] / wc))
@@ -56,7 +56,7 @@ try:
     P("")
     P("# second SQ pass (niter=10), per launch")
     for k in s2:
-        if not any(s in k for s in ("chain_kernel", "stream_kernel", "stream2_kernel")): continue
+        if not any(s in k for s in ("chain_kernel", "stream_kernel", "stream2_kernel", "rot_kernel")): continue
         P("%-92s launches %d" % (k, len(s2n[k])))
         for c in sorted(s2[k]): P("    %-28s %16.0f per launch" % (c, s2[k][c] / len(s2n[k])))
 except Exception as e:
