@@ -230,12 +230,15 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
       // them -- the only scratch of the kernel, and a kernel with scratch pays a scratch-memory set-up per dispatch.
       const unsigned rowF = (unsigned)nrow * (unsigned)a.Fs;                     // first element of the frame's row
       const unsigned uF = (unsigned)utt * (unsigned)a.Fs;
+      int qo = q;                                            // (opaque: the per-tile bin numbers are recomputed here, once per
+      asm volatile("" : "+v"(qo));                           //  wave tile, instead of being hoisted out of the loop and spilled)
+      auto bin0o = [&](int t) { return (!SPLIT && t < Tm) ? 32 * (t >> 1) + 8 * qo + 4 * (t & 1) : 16 * t + 4 * qo; };
 #pragma unroll
       for (int t = 0; t < MAXT; ++t) {
         x2[t] = f32x4{0, 0, 0, 0};
         vb[t] = f32x4{1, 1, 1, 1};
         if (tile_on(t)) {
-          const int f0 = bin0(t);
+          const int f0 = bin0o(t);
           f32x4 xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x2in_rs, (rowF + (unsigned)f0) * 4u, 0, 0));
           f32x4 v = {0, 0, 0, 0};
           if (a.Vb) {

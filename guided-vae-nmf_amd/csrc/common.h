@@ -81,6 +81,15 @@ struct vaenmf_plan {
   std::vector<hipEvent_t> prof_ev;      // pairs (start, stop)
   std::vector<int> prof_kind;
   size_t prof_used;
+  // vaenmf_em_run as a HIP graph: the ~600 launches of a call captured once per call signature and replayed, so that
+  // the launch path needs the host once per call instead of once per kernel (a loaded host showed as up to 20 % of
+  // idle GPU time between the kernels)
+  hipStream_t cap_stream = nullptr;     // capture needs a stream of its own (the caller's may be the null stream)
+  hipGraphExec_t g_exec = nullptr;
+  std::vector<uint64_t> g_key;          // signature of the captured call
+  std::vector<uint64_t> g_last;         // signature of the previous eager call (capture on its first repetition)
+  bool g_off = false;                   // capture failed once on this plan: stay eager
+  int last_em_graph = 0;                // VAENMF_Q_EM_GRAPH: 1 when the last vaenmf_em_run was a graph launch
 };
 
 // one MH-chain call, as vaenmf_mh_chain hands it to the kernel launchers (engine.hip team kernel, chain.hip wave kernel)

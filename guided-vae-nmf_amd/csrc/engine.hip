@@ -16,6 +16,7 @@
 // PREC: bf16x3 computes w_hi*a_hi + w_lo*a_hi + w_hi*a_lo (error ~2^-17 per product);
 //       bf16 computes w_hi*a_hi only.
 #include "common.h"
+#include <cstring>
 
 namespace {
 
@@ -1549,22 +1550,12 @@ extern "C" int vaenmf_wiener(vaenmf_plan* p, const float* X2, const float* W, co
   return 0;
 }
 
-extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* Ht, float* g, float* Z, const float* B1,
-                             float* Zs, int32_t Rcap, int32_t niter, int32_t nsE, int32_t biE, int32_t nsWF, int32_t biWF,
-                             float var_rw, const float* X, float* S_hat, float* N_hat, double* cost, void* stream) {
-  if (int e = check_bound(p)) return e;
-  VN_REQUIRE(nsE <= Rcap && nsWF <= Rcap, "Rcap=%d too small for nsE=%d / nsWF=%d", Rcap, nsE, nsWF);
+// the body of vaenmf_em_run: every launch on `stream`
+static int em_run_body(vaenmf_plan* p, const float* X2, float* W, float* Ht, float* g, float* Z, const float* B1, float* Zs,
+                       int32_t Rcap, int32_t niter, int32_t nsE, int32_t biE, int32_t nsWF, int32_t biWF, float var_rw,
+                       const float* X, float* S_hat, float* N_hat, double* cost, bool stored, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   vaenmf_rng rng = {VAENMF_RNG_DEVICE, 0, nullptr, nullptr};
-  // with the sample store on (vaenmf_sample_store), the chain leaves the samples' variances in HBM and the
-  // M-step / Wiener filter stream them; otherwise they decode Zs again
-  // (a batch too large for the store's 32-bit element offsets, or for the streaming kernels' bin range, decodes)
-  const size_t esz = p->cfg.precision == VAENMF_PREC_BF16X3 ? sizeof(float) : sizeof(__bf16);
-  auto fits = [&](int ns) { return (size_t)(p->NT + 1) * (ns + 1) * p->Fs * esz < 0xE0000000ull && p->Fm <= 768; };
-  const bool want = p->store_on, stored = want && fits(nsE) && fits(nsWF);
-  p->store_on = stored;
-  p->last_m_step_path = stored ? 1 : 2;               // VAENMF_Q_MSTEP_PATH: the caller can see a fall back to decoding
-  struct Restore { vaenmf_plan* p; bool v; ~Restore() { p->store_on = v; } } restore{p, want};
   for (int it = 0; it < niter; ++it) {                  // EM.run, mcem.py:159-165
     rng.call = (uint32_t)it;
     if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, 1, B1, Zs, Rcap, nsE, biE, var_rw, &rng, nullptr, stream)) return e;
@@ -1576,6 +1567,76 @@ extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* H
   if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, 0, B1, Zs, Rcap, nsWF, biWF, var_rw, &rng, nullptr, stream)) return e;
   if (stored) return vaenmf_wiener_stored(p, W, Ht, g, X, S_hat, N_hat, nullptr, nullptr, stream);
   return vaenmf_wiener(p, X2, W, Ht, g, Zs, Rcap, nsWF, B1, X, S_hat, N_hat, nullptr, nullptr, stream);
+}
+
+extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* Ht, float* g, float* Z, const float* B1,
+                             float* Zs, int32_t Rcap, int32_t niter, int32_t nsE, int32_t biE, int32_t nsWF, int32_t biWF,
+                             float var_rw, const float* X, float* S_hat, float* N_hat, double* cost, void* stream) {
+  if (int e = check_bound(p)) return e;
+  VN_REQUIRE(nsE <= Rcap && nsWF <= Rcap, "Rcap=%d too small for nsE=%d / nsWF=%d", Rcap, nsE, nsWF);
+  hipStream_t st = (hipStream_t)stream;
+  // with the sample store on (vaenmf_sample_store), the chain leaves the samples' variances in HBM and the
+  // M-step / Wiener filter stream them; otherwise they decode Zs again
+  // (a batch too large for the store's 32-bit element offsets, or for the streaming kernels' bin range, decodes)
+  const size_t esz = p->cfg.precision == VAENMF_PREC_BF16X3 ? sizeof(float) : sizeof(__bf16);
+  auto fits = [&](int ns) { return (size_t)(p->NT + 1) * (ns + 1) * p->Fs * esz < 0xE0000000ull && p->Fm <= 768; };
+  const bool want = p->store_on, stored = want && fits(nsE) && fits(nsWF);
+  p->store_on = stored;
+  p->last_m_step_path = stored ? 1 : 2;               // VAENMF_Q_MSTEP_PATH: the caller can see a fall back to decoding
+  struct Restore { vaenmf_plan* p; bool v; ~Restore() { p->store_on = v; } } restore{p, want};
+  auto eager = [&]() { return em_run_body(p, X2, W, Ht, g, Z, B1, Zs, Rcap, niter, nsE, biE, nsWF, biWF, var_rw, X, S_hat, N_hat, cost, stored, stream); };
+
+  // ---- HIP graph of the whole call.  The kernels' arguments are values and device pointers; a call with the same
+  // signature (buffers, shapes, counts) as the one before it is captured once and replayed from then on.  Contents that
+  // change from batch to batch -- spectrogram, seeds, frame tables -- live behind those pointers and are read at run time.
+  static const bool graphs_on = []() { const char* e = getenv("VAENMF_GRAPH"); return !(e && e[0] == '0'); }();
+  p->last_em_graph = 0;
+  if (!graphs_on || p->g_off || p->prof_on) return eager();
+  auto u64 = [](const void* q) { return (uint64_t)(uintptr_t)q; };
+  uint32_t vbits;
+  memcpy(&vbits, &var_rw, 4);
+  const std::vector<uint64_t> key = {
+      u64(X2), u64(W), u64(Ht), u64(g), u64(Z), u64(B1), u64(Zs), u64(X), u64(S_hat), u64(N_hat), u64(cost),
+      (uint64_t)Rcap, (uint64_t)niter, (uint64_t)nsE, (uint64_t)biE, (uint64_t)nsWF, (uint64_t)biWF, (uint64_t)vbits, (uint64_t)stored,
+      (uint64_t)p->NT, (uint64_t)p->n_utt, (uint64_t)p->n_wtiles, (uint64_t)p->n_tiles, u64(p->VsS), u64(p->src), u64(p->Vb_ext),
+      (uint64_t)p->VsS_cap, (uint64_t)p->Rcap_store, u64(p->w1f), u64(p->w2f), u64(p->w3f), u64(p->w3c), u64(p->b3c), u64(p->b1),
+      u64(p->d_wt_utt), u64(p->d_wt_n0), u64(p->d_wt_cnt), u64(p->d_frame_off), u64(p->d_frame_utt), u64(p->d_frame_loc), u64(p->d_tile_utt),
+      u64(p->d_tile_n0), u64(p->d_tile_cnt), u64(p->d_utt_seed), u64(p->A1), u64(p->P), u64(p->normW), u64(p->wpart), u64(p->cost_frames), u64(p->w3n), u64(p->w1y), u64(p->b2), u64(p->b3),
+      (uint64_t)p->cfg.precision, (uint64_t)p->cfg.K, (uint64_t)p->cfg.F};
+  auto after_replay = [&]() {                           // the host-side state an eager call leaves behind
+    if (stored) { p->store_R = nsWF; p->store_Rs = nsWF + 1; }
+  };
+  if (p->g_exec && key == p->g_key) {
+    VN_CHECK_HIP(hipGraphLaunch(p->g_exec, st));
+    after_replay();
+    p->last_em_graph = 1;
+    return 0;
+  }
+  if (key != p->g_last) {                               // first call of this signature: eager (it also sets every kernel attribute)
+    p->g_last = key;
+    return eager();
+  }
+  // second call in a row with this signature: capture
+  if (p->g_exec) { (void)hipGraphExecDestroy(p->g_exec); p->g_exec = nullptr; p->g_key.clear(); }
+  if (!p->cap_stream && hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking) != hipSuccess) { p->g_off = true; return eager(); }
+  hipGraph_t graph = nullptr;
+  if (hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); p->g_off = true; return eager(); }
+  const int rc = em_run_body(p, X2, W, Ht, g, Z, B1, Zs, Rcap, niter, nsE, biE, nsWF, biWF, var_rw, X, S_hat, N_hat, cost, stored, (void*)p->cap_stream);
+  const hipError_t ec = hipStreamEndCapture(p->cap_stream, &graph);
+  if (rc != 0 || ec != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    p->g_off = true;
+    return eager();
+  }
+  const hipError_t ei = hipGraphInstantiate(&p->g_exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess) { (void)hipGetLastError(); p->g_exec = nullptr; p->g_off = true; return eager(); }
+  p->g_key = key;
+  VN_CHECK_HIP(hipGraphLaunch(p->g_exec, st));
+  after_replay();
+  p->last_em_graph = 1;
+  return 0;
 }
 
 #ifdef VN_STAMP

@@ -165,6 +165,8 @@ extern "C" void vaenmf_plan_destroy(vaenmf_plan* p) {
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
+  if (p->g_exec) (void)hipGraphExecDestroy(p->g_exec);
+  if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
   delete p;
 }
 
@@ -178,6 +180,7 @@ extern "C" int vaenmf_plan_query(const vaenmf_plan* p, int32_t what) {
     case VAENMF_Q_NUTT: return p->n_utt;
     case VAENMF_Q_MSTEP_PATH: return p->last_m_step_path;
     case VAENMF_Q_WTILES: return p->n_wtiles;
+    case VAENMF_Q_EM_GRAPH: return p->last_em_graph;
     default: return -1;
   }
 }

@@ -79,6 +79,8 @@ struct FrameCtx {
   int lane;
   bool cv[NCH];                // chunk c holds real bins for this lane
   int f0[NCH];
+  unsigned fo[NCH];            // cv ? f0 : 0 as an unsigned element offset: (uniform row pointer)[fo] is addressed as SGPR base + 32-bit
+                               // VGPR offset, no 64-bit address pair per load in vector registers
   bool has_x;                  // an extra bin F-1 beside the 4-bin chunks
   // W of the utterance in LDS.  Read from global memory per frame the rows dominate the L1 traffic: a lane's 4
   // rows are 128 B (rank 8) from the next lane's, so every load instruction touches 64 cache lines -- ~3500 line
@@ -98,7 +100,7 @@ struct FrameCtx {
   __device__ FrameCtx(const StreamArgs& a_, float* wl_) : a(a_), wl(wl_) {
     lane = threadIdx.x & 63;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) { f0[c] = 256 * c + 4 * lane; cv[c] = f0[c] < a.Fm; }
+    for (int c = 0; c < NCH; ++c) { f0[c] = 256 * c + 4 * lane; cv[c] = f0[c] < a.Fm; fo[c] = cv[c] ? (unsigned)f0[c] : 0u; }
     has_x = a.F != a.Fm;
     wutt = -1;
     blk_utt = -1;
@@ -128,8 +130,13 @@ struct FrameCtx {
   __device__ __forceinline__ void set_utt(int utt, const float* normW = nullptr) {        // wave-uniform
     if (utt != xutt) {
       xutt = utt;
-      wx = (has_x && lane < KP) ? a.W[((size_t)utt * a.Fs + a.F - 1) * KP + lane] : 0.f;
-      if (normW) nw = lane < KP ? normW[(size_t)utt * KP + lane] : 1.f;
+      // (uniform base + 32-bit lane offset, the lane number opaque: nothing of this rare branch is precomputed outside the
+      // frame loop and kept -- spilled -- across it)
+      unsigned lo = (unsigned)lane;
+      asm volatile("" : "+v"(lo));
+      const unsigned lk = lo < (unsigned)KP ? lo : 0u;
+      wx = (has_x && lo < (unsigned)KP) ? (a.W + ((size_t)utt * a.Fs + a.F - 1) * KP)[lk] : 0.f;
+      if (normW) nw = lo < (unsigned)KP ? (normW + (size_t)utt * KP)[lk] : 1.f;
       // retired inside the branch: merged with the other path as "maybe pending", their first use -- behind the row
       // loads -- would be waited for with vmcnt(0), i.e. together with every row
       __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
@@ -140,7 +147,9 @@ struct FrameCtx {
     wutt = utt;
     __builtin_amdgcn_wave_barrier();                        // earlier reads of the previous utterance's rows
     const f32x4* src = reinterpret_cast<const f32x4*>(a.W + (size_t)utt * a.Fs * KP);
-    for (int e = lane; e < a.Fs * KP / 4; e += 64) put_t(e, src[e]);
+    unsigned e0 = (unsigned)lane;
+    asm volatile("" : "+v"(e0));
+    for (unsigned e = e0; e < (unsigned)(a.Fs * KP / 4); e += 64u) put_t((int)e, src[e]);
     __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the rows are in LDS (gfx9 encoding)
     __builtin_amdgcn_wave_barrier();
   }
@@ -241,22 +250,24 @@ struct FrameCtx {
     else w_dot_<false>(utt, k, P, A, px, ax, nu, de);
   }
   __device__ __forceinline__ void ext_var(int n, f32x4 (&vb)[NCH], float& vbx) const {   // caller-given Vb (noNMF)
+    const float* row = a.Vb + (size_t)n * a.Fs;
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
-      vb[c] = cv[c] ? *reinterpret_cast<const f32x4*>(a.Vb + (size_t)n * a.Fs + f0[c]) : f32x4{1.f, 1.f, 1.f, 1.f};
-    vbx = has_x ? a.Vb[(size_t)n * a.Fs + a.F - 1] : 1.f;
+      vb[c] = cv[c] ? *reinterpret_cast<const f32x4*>(row + fo[c]) : f32x4{1.f, 1.f, 1.f, 1.f};
+    vbx = has_x ? row[a.F - 1] : 1.f;
   }
   __device__ __forceinline__ void load_x2(int n, f32x4 (&x2)[NCH], float& x2x) const {
+    const float* row = a.X2 + (size_t)n * a.Fs;
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
-      x2[c] = cv[c] ? *reinterpret_cast<const f32x4*>(a.X2 + (size_t)n * a.Fs + f0[c]) : f32x4{0.f, 0.f, 0.f, 0.f};
-    x2x = has_x ? a.X2[(size_t)n * a.Fs + a.F - 1] : 0.f;
+      x2[c] = cv[c] ? *reinterpret_cast<const f32x4*>(row + fo[c]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    x2x = has_x ? row[a.F - 1] : 0.f;
   }
   // write a per-bin result row (bins >= F zeroed)
   __device__ __forceinline__ void store_row(float* dst, const f32x4 (&v)[NCH], float vx) const {
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
-      if (cv[c]) *reinterpret_cast<f32x4*>(dst + f0[c]) = v[c];
+      if (cv[c]) *reinterpret_cast<f32x4*>(dst + fo[c]) = v[c];
     if (a.Fm + lane < a.Fs) dst[a.Fm + lane] = (lane == 0 && has_x) ? vx : 0.f;
   }
 };
@@ -287,7 +298,8 @@ struct RowBatch {
   template <typename FC>
   static __device__ __forceinline__ int load_slots(const FC& fc, const int32_t* scol, int r0, int R) {
     const int nr_ = R - r0 < RB ? R - r0 : RB;
-    return scol[(size_t)(r0 + (fc.lane < nr_ ? fc.lane : 0)) * fc.a.NT];
+    // (a 32-bit BYTE offset from a uniform base: SGPR pair + one VGPR, no 64-bit address pair kept -- and spilled -- per lane)
+    return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(scol) + (unsigned)(r0 + (fc.lane < nr_ ? fc.lane : 0)) * (unsigned)fc.a.NT * 4u);
   }
   // rows r0 .. r0+nr-1 of the frame whose store block starts at `base`, slots from load_slots
   template <typename FC>
@@ -305,7 +317,7 @@ struct RowBatch {
         const ST* row = base + (size_t)__builtin_amdgcn_readlane(sl, r) * fc.a.Fs;
 #endif
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) raw[r][c] = *reinterpret_cast<const raw_t*>(row + (fc.cv[c] ? fc.f0[c] : 0));
+        for (int c = 0; c < NCH; ++c) raw[r][c] = *reinterpret_cast<const raw_t*>(row + fc.fo[c]);
       }
     // extra bin, raw bits (x() converts at the use: a conversion here would wait for every load above)
     if (fc.has_x) {
@@ -943,7 +955,7 @@ struct RotCtx {
     else { pk_base = reinterpret_cast<const char*>(a.g); pk_stride = 4u; }
   }
   __device__ __forceinline__ int slots(int n) const {       // lane j: slot of row j of frame n (sample-major map)
-    return a.src[(size_t)(fc.lane < RT ? fc.lane : 0) * a.NT + n];
+    return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.src + n) + (unsigned)(fc.lane < RT ? fc.lane : 0) * (unsigned)a.NT * 4u);
   }
   __device__ __forceinline__ void req_small(int n, RotSmall<KP>& s) const {
     s.pk = *reinterpret_cast<const float*>(pk_base + (size_t)n * pk_stride);

@@ -99,6 +99,9 @@ class BatchEngine:
             self._bZ = torch.empty(MF, LAT, device=dev, dtype=f32)
             self._bZs = torch.empty(MF, self.Rcap, LAT, device=dev, dtype=f32)
             self._bcost = torch.empty(MF, device=dev, dtype=torch.float64)
+            self._bS = torch.empty(MF, Fs, 2, device=dev, dtype=f32)      # outputs of run(): fixed addresses, so that a repeated
+            self._bN = torch.empty(MF, Fs, 2, device=dev, dtype=f32)      # call has the signature vaenmf_em_run replays as a graph
+            self._bcu = {}                                                # niter -> [max_utts, niter] float64
             self._cap_key = self.Rcap
         self.X, self.X2, self.W, self.Ht = self._bX[:NT], self._bX2[:NT], self._bW[:self.U], self._bHt[:NT]
         self.g, self.Z, self.Zs, self.cost_frames = self._bg[:NT], self._bZ[:NT], self._bZs[:NT], self._bcost[:NT]
@@ -252,9 +255,11 @@ class BatchEngine:
         store: use the sample-variance store (include/vaenmf.h); default: on (bf16 rows in bf16 mode, float rows in
         bf16x3 mode; vaenmf_em_run falls back to the decoding M-step when a batch's store would pass 3.5 GB --
         VAENMF_Q_MSTEP_PATH tells which path ran)."""
-        cost = torch.zeros(self.U, niter, device=self.device, dtype=torch.float64)
-        S = torch.empty_like(self.X)
-        N = torch.empty_like(self.X)
+        if int(niter) not in self._bcu:
+            self._bcu[int(niter)] = torch.empty(self._max_utts * int(niter), device=self.device, dtype=torch.float64)
+        cost = self._bcu[int(niter)][:self.U * int(niter)].view(self.U, int(niter))
+        cost.zero_()
+        S, N = self._bS[:self.NT], self._bN[:self.NT]
         if store is None:       # the chain keeps the samples' variances in HBM, M-step and Wiener filter stream them
             store = self.F <= 769
         self.sample_store(store)
@@ -262,7 +267,7 @@ class BatchEngine:
                                   _ptr(self.B1), _ptr(self.Zs), self.Rcap, int(niter), int(nsE), int(biE), int(nsWF),
                                   int(biWF), float(var_rw), _ptr(self.X), _ptr(S), _ptr(N), _ptr(cost), _stream()))
         self.sample_store(False)
-        return cost, S, N
+        return cost.clone(), S.clone(), N.clone()      # (the buffers are overwritten by the next run)
 
     # ------------------------------------------------------------------ host views (reference shapes)
     def Vb(self, u):

@@ -53,7 +53,8 @@ enum { VAENMF_RNG_REPLAY = 0,    /* caller supplies the normal / uniform draws (
 
 enum { VAENMF_Q_FS = 0, VAENMF_Q_KP = 1, VAENMF_Q_TILES = 2, VAENMF_Q_NT = 3, VAENMF_Q_NUTT = 4,
        VAENMF_Q_MSTEP_PATH = 5,  /* M-step path of the last vaenmf_em_run: 1 = streaming the sample store, 2 = decoding */
-       VAENMF_Q_WTILES = 6 };    /* 16-frame wave tiles of the bound batch */
+       VAENMF_Q_WTILES = 6,      /* 16-frame wave tiles of the bound batch */
+       VAENMF_Q_EM_GRAPH = 7 };  /* 1 when the last vaenmf_em_run was launched as a captured HIP graph, 0 when launch by launch */
 
 enum { VAENMF_ACT_NONE = 0, VAENMF_ACT_TANH = 1, VAENMF_ACT_RELU = 2, VAENMF_ACT_SIGMOID = 3,
        VAENMF_ACT_STEP = 4 };   /* 1 if x > 0 else 0: sigmoid(x) > 0.5, scripts/evaluate_M2_vad.py:131 */
@@ -149,7 +150,12 @@ int vaenmf_wiener(vaenmf_plan* p, const float* X2, const float* W, const float* 
  * chain and filter.  cost DEV [n_utt][niter] double.  (nsE, biE) / (nsWF, biWF) are the
  * EFFECTIVE sample/burn-in counts (the caller applies MCEM_M1's positional-shift quirk,
  * mcem.py:461-462).  Device RNG only (rng_mode REPLAY is served step by step by the
- * calls above). */
+ * calls above).
+ * A call whose signature (buffers, shapes, counts) repeats the previous call's is captured into a
+ * HIP graph once and replayed from then on -- one launch per call instead of ~600; the batch's
+ * contents (spectrogram, seeds, frame tables) sit behind the same pointers and are read at run
+ * time.  Profiling (vaenmf_profile_*) and VAENMF_GRAPH=0 keep the launch-by-launch path;
+ * results are the same either way. */
 int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* Ht, float* g, float* Z,
                   const float* B1, float* Zs, int32_t Rcap, int32_t niter,
                   int32_t nsE, int32_t biE, int32_t nsWF, int32_t biWF, float var_rw,

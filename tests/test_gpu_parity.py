@@ -721,6 +721,35 @@ def test_nonmf_fused_run_equals_stepwise():
     assert np.all(np.isfinite(outs[0][0])) and outs[0][0][-1] < outs[0][0][0] * 1.5
 
 
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+def test_em_run_graph_replay_equals_launch_by_launch(prec):
+    """vaenmf_em_run captures a call whose signature repeats into a HIP graph and replays it.  The same batch with the
+    same seeds through the pipeline four times: call 1 runs launch by launch, call 2 captures and launches the graph,
+    calls 3 and 4 replay it -- every output bit for bit equal to call 1's, a different seed gives a different result
+    through the same graph (the batch's contents are read at run time, not baked in), and VAENMF_Q_EM_GRAPH says
+    which path ran."""
+    need_gpu()
+    from vaenmf.pipeline import Reconstructor
+    from vaenmf import _lib
+    F, K, T, U = 257, 8, 4000, 3
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=5)
+    dev = torch.device("cuda:0")
+    wav = torch.from_numpy(np.concatenate([orc.synth_utterance(u, T)[2] for u in range(U)]).astype(np.float32)).to(dev)
+    rec = Reconstructor(params, F, K, niter=4, fs=16000, wlen_sec=0.032, precision=prec, device=dev, max_frames=U * (T // 128 + 8), max_utts=U)
+    q = lambda: _lib.lib().vaenmf_plan_query(rec.eng._plan, _lib.Q_EM_GRAPH)
+    outs, paths = [], []
+    for call in range(4):
+        s_hat, n_hat, cost = rec.enhance(wav, [T] * U, seeds=[11, 12, 13], init_seed=3)
+        outs.append((s_hat.cpu().numpy().copy(), n_hat.cpu().numpy().copy(), cost.cpu().numpy().copy()))
+        paths.append(q())
+    assert paths == [0, 1, 1, 1], paths
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
+    s2, _, c2 = rec.enhance(wav, [T] * U, seeds=[21, 22, 23], init_seed=4)        # same shapes: still the graph
+    assert q() == 1
+    assert not np.array_equal(s2.cpu().numpy(), outs[0][0]) and np.all(np.isfinite(c2.cpu().numpy()))
+
+
 def test_label_front_ends_bit_exact():
     """vaenmf.target (csrc/labels.hip) against the reference's own outputs (tests/golden/labels_f257.npz,
     generated by importing python/processing/target.py): every 0/1 label identical, thresholds identical."""
