@@ -85,9 +85,10 @@ struct vaenmf_plan {
   // the launch path needs the host once per call instead of once per kernel (a loaded host showed as up to 20 % of
   // idle GPU time between the kernels)
   hipStream_t cap_stream = nullptr;     // capture needs a stream of its own (the caller's may be the null stream)
-  hipGraphExec_t g_exec = nullptr;
-  std::vector<uint64_t> g_key;          // signature of the captured call
-  std::vector<uint64_t> g_last;         // signature of the previous eager call (capture on its first repetition)
+  struct EmGraph { std::vector<uint64_t> key; hipGraphExec_t exec; uint64_t used; };
+  std::vector<EmGraph> g_cache;         // captured calls, a few signatures (a job alternates batch shapes: 63 / 62 utterances)
+  std::vector<std::vector<uint64_t>> g_seen;   // signatures run eagerly once (a signature is captured at its second appearance)
+  uint64_t g_tick = 0;
   bool g_off = false;                   // capture failed once on this plan: stay eager
   int last_em_graph = 0;                // VAENMF_Q_EM_GRAPH: 1 when the last vaenmf_em_run was a graph launch
 };

@@ -1586,8 +1586,8 @@ extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* H
   struct Restore { vaenmf_plan* p; bool v; ~Restore() { p->store_on = v; } } restore{p, want};
   auto eager = [&]() { return em_run_body(p, X2, W, Ht, g, Z, B1, Zs, Rcap, niter, nsE, biE, nsWF, biWF, var_rw, X, S_hat, N_hat, cost, stored, stream); };
 
-  // ---- HIP graph of the whole call.  The kernels' arguments are values and device pointers; a call with the same
-  // signature (buffers, shapes, counts) as the one before it is captured once and replayed from then on.  Contents that
+  // ---- HIP graph of the whole call.  The kernels' arguments are values and device pointers; a signature (buffers,
+  // shapes, counts) is captured at its second appearance and replayed from then on (a few signatures are kept).  Contents that
   // change from batch to batch -- spectrogram, seeds, frame tables -- live behind those pointers and are read at run time.
   static const bool graphs_on = []() { const char* e = getenv("VAENMF_GRAPH"); return !(e && e[0] == '0'); }();
   p->last_em_graph = 0;
@@ -1606,18 +1606,23 @@ extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* H
   auto after_replay = [&]() {                           // the host-side state an eager call leaves behind
     if (stored) { p->store_R = nsWF; p->store_Rs = nsWF + 1; }
   };
-  if (p->g_exec && key == p->g_key) {
-    VN_CHECK_HIP(hipGraphLaunch(p->g_exec, st));
-    after_replay();
-    p->last_em_graph = 1;
-    return 0;
-  }
-  if (key != p->g_last) {                               // first call of this signature: eager (it also sets every kernel attribute)
-    p->g_last = key;
+  constexpr size_t MAX_GRAPHS = 4, MAX_SEEN = 8;
+  for (auto& gph : p->g_cache)
+    if (gph.key == key) {
+      VN_CHECK_HIP(hipGraphLaunch(gph.exec, st));
+      gph.used = ++p->g_tick;
+      after_replay();
+      p->last_em_graph = 1;
+      return 0;
+    }
+  bool seen = false;
+  for (auto& k : p->g_seen) seen = seen || k == key;
+  if (!seen) {                                          // first call of this signature: eager (it also sets every kernel attribute)
+    if (p->g_seen.size() >= MAX_SEEN) p->g_seen.erase(p->g_seen.begin());
+    p->g_seen.push_back(key);
     return eager();
   }
-  // second call in a row with this signature: capture
-  if (p->g_exec) { (void)hipGraphExecDestroy(p->g_exec); p->g_exec = nullptr; p->g_key.clear(); }
+  // second appearance of the signature: capture
   if (!p->cap_stream && hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking) != hipSuccess) { p->g_off = true; return eager(); }
   hipGraph_t graph = nullptr;
   if (hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); p->g_off = true; return eager(); }
@@ -1629,11 +1634,18 @@ extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* H
     p->g_off = true;
     return eager();
   }
-  const hipError_t ei = hipGraphInstantiate(&p->g_exec, graph, nullptr, nullptr, 0);
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
-  if (ei != hipSuccess) { (void)hipGetLastError(); p->g_exec = nullptr; p->g_off = true; return eager(); }
-  p->g_key = key;
-  VN_CHECK_HIP(hipGraphLaunch(p->g_exec, st));
+  if (ei != hipSuccess || !exec) { (void)hipGetLastError(); p->g_off = true; return eager(); }
+  if (p->g_cache.size() >= MAX_GRAPHS) {                // evict the least recently used
+    size_t lru = 0;
+    for (size_t i = 1; i < p->g_cache.size(); ++i) if (p->g_cache[i].used < p->g_cache[lru].used) lru = i;
+    (void)hipGraphExecDestroy(p->g_cache[lru].exec);
+    p->g_cache.erase(p->g_cache.begin() + lru);
+  }
+  p->g_cache.push_back({key, exec, ++p->g_tick});
+  VN_CHECK_HIP(hipGraphLaunch(exec, st));
   after_replay();
   p->last_em_graph = 1;
   return 0;

@@ -165,7 +165,7 @@ extern "C" void vaenmf_plan_destroy(vaenmf_plan* p) {
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
-  if (p->g_exec) (void)hipGraphExecDestroy(p->g_exec);
+  for (auto& gph : p->g_cache) if (gph.exec) (void)hipGraphExecDestroy(gph.exec);
   if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
   delete p;
 }

@@ -726,8 +726,8 @@ def test_em_run_graph_replay_equals_launch_by_launch(prec):
     """vaenmf_em_run captures a call whose signature repeats into a HIP graph and replays it.  The same batch with the
     same seeds through the pipeline four times: call 1 runs launch by launch, call 2 captures and launches the graph,
     calls 3 and 4 replay it -- every output bit for bit equal to call 1's, a different seed gives a different result
-    through the same graph (the batch's contents are read at run time, not baked in), and VAENMF_Q_EM_GRAPH says
-    which path ran."""
+    through the same graph (the batch's contents are read at run time, not baked in), a second batch shape alternating
+    with the first gets a graph of its own, and VAENMF_Q_EM_GRAPH says which path ran."""
     need_gpu()
     from vaenmf.pipeline import Reconstructor
     from vaenmf import _lib
@@ -748,6 +748,16 @@ def test_em_run_graph_replay_equals_launch_by_launch(prec):
     s2, _, c2 = rec.enhance(wav, [T] * U, seeds=[21, 22, 23], init_seed=4)        # same shapes: still the graph
     assert q() == 1
     assert not np.array_equal(s2.cpu().numpy(), outs[0][0]) and np.all(np.isfinite(c2.cpu().numpy()))
+    # a job that alternates two batch shapes (config 4: 63 / 62 utterances) keeps one graph per signature
+    wavB, cntB = wav[:2 * T].contiguous(), [T] * 2
+    resB, pathsB = [], []
+    for call in range(3):
+        sB, _, _ = rec.enhance(wavB, cntB, seeds=[31, 32], init_seed=9)
+        resB.append(sB.cpu().numpy().copy()); pathsB.append(q())
+        sA, _, _ = rec.enhance(wav, [T] * U, seeds=[11, 12, 13], init_seed=3)
+        assert q() == 1 and np.array_equal(sA.cpu().numpy(), outs[0][0])
+    assert pathsB == [0, 1, 1], pathsB
+    assert np.array_equal(resB[1], resB[0]) and np.array_equal(resB[2], resB[0])
 
 
 def test_label_front_ends_bit_exact():
