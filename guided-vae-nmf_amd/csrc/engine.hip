@@ -1577,9 +1577,10 @@ extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* H
   hipStream_t st = (hipStream_t)stream;
   // with the sample store on (vaenmf_sample_store), the chain leaves the samples' variances in HBM and the
   // M-step / Wiener filter stream them; otherwise they decode Zs again
-  // (a batch too large for the store's 32-bit element offsets, or for the streaming kernels' bin range, decodes)
+  // (a batch too large for the store's 32-bit element offsets decodes; every F the plan accepts, <= 640, is in the streaming
+  // kernels' bin range)
   const size_t esz = p->cfg.precision == VAENMF_PREC_BF16X3 ? sizeof(float) : sizeof(__bf16);
-  auto fits = [&](int ns) { return (size_t)(p->NT + 1) * (ns + 1) * p->Fs * esz < 0xE0000000ull && p->Fm <= 768; };
+  auto fits = [&](int ns) { return (size_t)(p->NT + 1) * (ns + 1) * p->Fs * esz < 0xE0000000ull; };
   const bool want = p->store_on, stored = want && fits(nsE) && fits(nsWF);
   p->store_on = stored;
   p->last_m_step_path = stored ? 1 : 2;               // VAENMF_Q_MSTEP_PATH: the caller can see a fall back to decoding

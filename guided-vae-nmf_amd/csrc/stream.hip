@@ -1166,7 +1166,6 @@ int launch_stream(const vaenmf_plan* p, const StreamArgs& a, hipStream_t st) {
 int check_store(const vaenmf_plan* p) {
   VN_REQUIRE(p != nullptr && p->have_weights && p->NT > 0, "plan not ready");
   VN_REQUIRE(p->store_R > 0, "the sample store is empty: vaenmf_sample_store(plan, 1), then vaenmf_mh_chain");
-  VN_REQUIRE(p->Fm <= 768, "F = %d: the streaming kernels cover up to 769 bins", p->cfg.F);
   return 0;
 }
 

@@ -261,7 +261,7 @@ class BatchEngine:
         cost.zero_()
         S, N = self._bS[:self.NT], self._bN[:self.NT]
         if store is None:       # the chain keeps the samples' variances in HBM, M-step and Wiener filter stream them
-            store = self.F <= 769
+            store = True
         self.sample_store(store)
         check(lib().vaenmf_em_run(self._plan, _ptr(self.X2), _ptr(self.W), _ptr(self.Ht), _ptr(self.g), _ptr(self.Z),
                                   _ptr(self.B1), _ptr(self.Zs), self.Rcap, int(niter), int(nsE), int(biE), int(nsWF),
