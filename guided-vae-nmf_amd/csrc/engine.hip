@@ -1596,7 +1596,9 @@ extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* H
   auto u64 = [](const void* q) { return (uint64_t)(uintptr_t)q; };
   uint32_t vbits;
   memcpy(&vbits, &var_rw, 4);
-  const std::vector<uint64_t> key = {
+  uint64_t fo_hash = 1469598103934665603ull;            // the batch's frame offsets (FNV-1a): launches derive grids and chunk tables from them
+  for (int32_t v : p->h_frame_off) { fo_hash ^= (uint64_t)(uint32_t)v; fo_hash *= 1099511628211ull; }
+  const std::vector<uint64_t> key = {fo_hash,
       u64(X2), u64(W), u64(Ht), u64(g), u64(Z), u64(B1), u64(Zs), u64(X), u64(S_hat), u64(N_hat), u64(cost),
       (uint64_t)Rcap, (uint64_t)niter, (uint64_t)nsE, (uint64_t)biE, (uint64_t)nsWF, (uint64_t)biWF, (uint64_t)vbits, (uint64_t)stored,
       (uint64_t)p->NT, (uint64_t)p->n_utt, (uint64_t)p->n_wtiles, (uint64_t)p->n_tiles, u64(p->VsS), u64(p->src), u64(p->Vb_ext),

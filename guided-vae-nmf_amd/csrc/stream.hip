@@ -30,6 +30,9 @@
 #ifndef VN_WS_EXACT
 #define VN_WS_EXACT 0     // exact-sample-count instantiations of wstats_stream2 (R = 30 / 10)
 #endif
+#ifndef VN_HG_FULL2
+#define VN_HG_FULL2 1
+#endif
 #ifndef VN_HG_EXACT
 #define VN_HG_EXACT 1     // exact-sample-count instantiations of hg_stream (R = 30 / 10, one chunk, rank <= 8): no per-row branches, rows consumed
                           // as they arrive (precise vmcnt counts): 0.198 -> 0.172 ms.  (Slower while the extra-bin addresses still spilled.)
@@ -282,9 +285,11 @@ __device__ __forceinline__ f32x2 log2_2(const f32x2 x) { return f32x2{fast_log2(
 // passes of hg_stream reuse the registers instead of reading the rows again when the frame fits one batch.
 // RT > 0: the frame has exactly RT rows (compile time: the row loops carry no checks, so the compiler interleaves the
 // rows' dependent chains); RT = 0: any row count up to RB (one uniform branch per row).
-template <int NCH, typename ST, int DIV = 1, int RT = 0>
+template <int NCH, typename ST, int DIV = 1, int RT = 0, int RBX = 0>
 struct RowBatch {
-  static constexpr int RB = (sizeof(ST) == 2 ? 32 : 16) / NCH / DIV;
+  // rows per batch; RBX > 0 overrides (hg_stream with two 256-bin chunks of bf16 rows: 32 rows x 4 registers hold a whole
+  // 30-sample frame, so its three passes read the rows once instead of re-reading two batches of 16 in every pass)
+  static constexpr int RB = RBX > 0 ? RBX : (sizeof(ST) == 2 ? 32 : 16) / NCH / DIV;
   static_assert(RT <= RB, "RT");
   __device__ __forceinline__ bool on(int r) const { return RT > 0 ? r < RT : r < nr; }
   using raw_t = typename std::conditional<sizeof(ST) == 4, f32x4, bf16x4>::type;
@@ -530,7 +535,8 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   FrameCtx<NCH, KP, ST> fc(a, wlds + (KP <= 8 ? (size_t)(threadIdx.x >> 6) * a.Fs * KP : 0));
   fc.stage_block_w();
-  using RBt = RowBatch<NCH, ST, 1, RT>;
+  // (two chunks, rank <= 16: 0.306 -> 0.286 ms on the 1024-pt shape; at rank 32 the registers do not suffice: 0.535 -> 0.608)
+  using RBt = RowBatch<NCH, ST, 1, RT, (VN_HG_FULL2 && sizeof(ST) == 2 && NCH == 2 && KP <= 16) ? 32 : 0>;
   int n_beg, n_end;
   wave_frames(a.NT, n_beg, n_end);
 #if VN_HG_STAGGER > 0

@@ -83,3 +83,65 @@ def test_si_sdr_and_cost_distribution_match_reference():
     dp = a - b
     print("paired bf16+store - bf16x3 (same streams): mean %+.4f dB, s.e. %.4f dB" % (dp.mean(), dp.std(ddof=1) / np.sqrt(dp.size)))
     assert abs(dp.mean()) <= 3 * dp.std(ddof=1) / np.sqrt(dp.size) + 1e-3
+
+
+def test_guided_m2_distribution_matches_reference():
+    """The guided model (MCEM_M2, BASELINE config 3, IBM labels: y_dim = F) with the device generator against the
+    imported reference's own outcome distribution (tests/golden/si_sdr_dist_m2.npz, make_si_sdr_dist_m2.py: MCEM_M2
+    unmodified, the same 8 synthetic utterances x 192 seeds, labels = hard IBM of the clean speech, committed with the
+    vector).  In bf16 mode the chain keeps the per-frame layer-1 bias rows as bf16 in LDS (8 wavefronts per workgroup);
+    this is the test that pins that mode of the guided path.  Tolerances as above: 3 sigma of the combined seed spreads on
+    the overall mean, 4 sigma per utterance and on the final cost."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vaenmf.pipeline import Reconstructor
+    from vaenmf import metrics as vm
+    from vaenmf import _lib
+    z = np.load(os.path.join(HERE, "golden", "si_sdr_dist_m2.npz"))
+    ref, lab = z["results"], z["labels"].astype(np.float32)             # [U, S, 4]; [U, N, F]
+    F, K, NITER, FS, WLEN, T = int(z["F"]), int(z["K"]), int(z["niter"]), int(z["fs"]), float(z["wlen"]), int(z["T"])
+    U, S = ref.shape[:2]
+    SB = 48
+    assert S % SB == 0
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=0, y_dim=F)
+    sig = [orc.synth_utterance(u, T) for u in range(U)]
+    dev = torch.device("cuda:0")
+    rep = lambda i: torch.from_numpy(np.concatenate([sg[i] for sg in sig] * SB).astype(np.float32)).to(dev)
+    wav_x, wav_s, wav_n = rep(2), rep(0), rep(1)
+    y = torch.from_numpy(np.concatenate([lab[u] for u in range(U)] * SB)).to(dev)       # [NT, F], utterance u of seed sd at sd * U + u
+    res = {}
+    for name, prec in (("bf16x3", "bf16x3"), ("bf16 + bf16 sample store (bench mode of config 3)", "bf16")):
+        rec = Reconstructor(params, F, K, niter=NITER, fs=FS, wlen_sec=WLEN, precision=prec, device=dev, model="M2",
+                            max_frames=U * SB * (T // 128 + 8), max_utts=U * SB)
+        sdrs, costs = [], []
+        for b in range(S // SB):
+            s_hat, n_hat, cost = rec.enhance(wav_x, [T] * (U * SB), seeds=[7919 * (b * U * SB + i) + 17 for i in range(U * SB)], init_seed=5 + b, y=y)
+            G = vm.gram3_batch(s_hat, wav_s, wav_n, [T] * (U * SB))
+            sdrs.append(np.asarray(vm.ratios_from_gram(G)[0]).reshape(SB, U).T)
+            costs.append(cost[:, -1].cpu().numpy().reshape(SB, U).T)
+        assert _lib.lib().vaenmf_plan_query(rec.eng._plan, _lib.Q_MSTEP_PATH) == 1
+        res[name] = np.stack([np.concatenate(sdrs, 1), np.concatenate(costs, 1)], 2)
+        del rec
+    r_sdr, r_cost = ref[:, :, 0], ref[:, :, 3]
+    se_ref_u = r_sdr.std(1, ddof=1) / np.sqrt(S)
+    se_ref = np.sqrt(np.sum(se_ref_u ** 2)) / U
+    for name, g in res.items():
+        g_sdr, g_cost = g[:, :, 0], g[:, :, 1]
+        se_gpu_u = g_sdr.std(1, ddof=1) / np.sqrt(S)
+        se_gpu = np.sqrt(np.sum(se_gpu_u ** 2)) / U
+        d = g_sdr.mean() - r_sdr.mean()
+        tol = 3 * np.sqrt(se_ref ** 2 + se_gpu ** 2)
+        d_u = g_sdr.mean(1) - r_sdr.mean(1)
+        tol_u = 4 * np.sqrt(se_ref_u ** 2 + se_gpu_u ** 2)
+        rc = g_cost.mean(1) / r_cost.mean(1) - 1
+        tol_c = 4 * np.sqrt((r_cost.std(1, ddof=1) / r_cost.mean(1)) ** 2 + (g_cost.std(1, ddof=1) / g_cost.mean(1)) ** 2) / np.sqrt(S)
+        print("M2 %s: mean SI-SDR gpu %.4f dB, reference %.4f dB: diff %+.4f dB (tolerance %.4f = 3 sigma; s.e. ref %.4f, gpu %.4f)\n"
+              "   per utterance diff (dB) %s  tol %s\n   relative final-cost diff %s  tol %s"
+              % (name, g_sdr.mean(), r_sdr.mean(), d, tol, se_ref, se_gpu, np.round(d_u, 3), np.round(tol_u, 3), np.round(rc, 5), np.round(tol_c, 5)))
+        assert abs(d) <= tol, (name, d, tol)
+        assert np.all(np.abs(d_u) <= tol_u), (name, d_u, tol_u)
+        assert np.all(np.abs(rc) <= tol_c), (name, rc, tol_c)
+    a, b = res["bf16 + bf16 sample store (bench mode of config 3)"][:, :, 0], res["bf16x3"][:, :, 0]
+    dp = a - b
+    print("M2 paired bf16+store - bf16x3 (same streams): mean %+.4f dB, s.e. %.4f dB" % (dp.mean(), dp.std(ddof=1) / np.sqrt(dp.size)))
+    assert abs(dp.mean()) <= 3 * dp.std(ddof=1) / np.sqrt(dp.size) + 1e-3
