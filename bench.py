@@ -150,9 +150,14 @@ def main():
 
     if not args.dry_run and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    dev = torch.device("cpu") if args.dry_run else torch.device("cuda", local_rank)
+    # rehearsal aid for one-GPU boxes: VAENMF_BENCH_SHARE_GPU=1 with --backend gloo runs every rank's compute on GPU 0 and
+    # the (tiny) collectives through gloo on host tensors -- the launcher, the sharding and the max-over-ranks clock on real
+    # kernels; never the measured configuration (RCCL refuses two ranks on one device)
+    share = os.environ.get("VAENMF_BENCH_SHARE_GPU") == "1" and args.backend == "gloo"
+    dev = torch.device("cpu") if args.dry_run else torch.device("cuda", 0 if share else local_rank)
+    comm_dev = torch.device("cpu") if (args.dry_run or args.backend == "gloo") else dev
     if not args.dry_run:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(dev.index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl" and not args.dry_run:
@@ -236,7 +241,7 @@ def main():
             G = vmet.gram3_batch(s_hat, ws, wn, counts)              # D2H of 6 doubles per utterance
             st = vmet.sufficient_stats(np.stack(vmet.ratios_from_gram(G), 1), snr)
             acc = st if acc is None else acc + st
-        return allreduce_stats(acc, dev), cost                       # RCCL all-reduce (<1 KB), once per step
+        return allreduce_stats(acc, comm_dev), cost                  # RCCL all-reduce (<1 KB), once per step
 
     note("workload ready: %d utterances on rank 0 in %d batch(es); warm-up" % (len(ids), len(batches)))
     for i in range(args.warmup):
@@ -249,8 +254,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     note("timed region: %.1f ms per step" % (dt / args.steps * 1e3))
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    nutt = torch.tensor([float(len(ids))], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
+    nutt = torch.tensor([float(len(ids))], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(nutt, op=dist.ReduceOp.SUM)
