@@ -368,7 +368,7 @@ def main():
         try:        # real HBM bytes per EM iteration from the committed PMC passes, against the measured iteration time
             tj = json.load(open(os.path.join(ROOT, "profiles", traffic_src.split("/", 1)[1])))
             per_iter = sum(v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()
-                           if any(s in k for s in ("chain_kernel", "wstats_stream", "hg_stream", "w_partial", "w_update")))
+                           if any(s in k for s in ("chain_kernel", "wstats_stream", "wstats_rot", "hg_stream", "w_partial", "w_update")))
             out["measured_hbm"] = {"bytes_per_em_iteration": per_iter, "GBps": per_iter / (iter_ms * 1e-3) / 1e9,
                                    "frac_of_8TBps": per_iter / (iter_ms * 1e-3) / PEAK_HBM,
                                    "note": "rocprofv3 PMC bytes (committed profile, not this run) / this run's kernel time per EM iteration"}
