@@ -374,6 +374,20 @@ def main():
                                    "note": "rocprofv3 PMC bytes (committed profile, not this run) / this run's kernel time per EM iteration"}
         except Exception:
             pass
+        try:        # what this GPU gives a plain streaming read (outside the timed region): the practical ceiling of the M-step kernels
+            probe = torch.empty(130 * 1024 * 1024, dtype=torch.float32, device=dev).fill_(1.0)      # 520 MB, the size of the sample store
+            probe.sum(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                probe.sum()
+            e1.record(); torch.cuda.synchronize()
+            out["stream_read_probe"] = {"GBps": probe.numel() * 4 / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9, "bytes": probe.numel() * 4,
+                                        "note": "torch.sum over a 520 MB float buffer, 10 repetitions: the read bandwidth a plain streaming kernel gets on this "
+                                                "GPU (the W-statistics kernel's rows + operands stream at about this rate); not part of the timed region"}
+            del probe
+        except Exception:
+            pass
         if configs:
             out["configs"] = configs
         if par is not None:
