@@ -33,6 +33,9 @@
 #ifndef VN_HG_FULL2
 #define VN_HG_FULL2 1
 #endif
+#ifndef VN_HG_FULL2_KMAX
+#define VN_HG_FULL2_KMAX 16     // (rank 32: the whole-frame batch still spills, 288 bytes, and gains nothing)
+#endif
 #ifndef VN_HG_EXACT
 #define VN_HG_EXACT 1     // exact-sample-count instantiations of hg_stream (R = 30 / 10, one chunk, rank <= 8): no per-row branches, rows consumed
                           // as they arrive (precise vmcnt counts): 0.198 -> 0.172 ms.  (Slower while the extra-bin addresses still spilled.)
@@ -75,6 +78,8 @@ struct StreamArgs {
 };
 
 __device__ __forceinline__ float wave_sum(float v) { return sum_rows4(sum_row16(v)); }
+// a value every lane holds alike, kept in a scalar register from here on
+__device__ __forceinline__ float vn_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 
 template <int NCH, int KP, typename ST>
 struct FrameCtx {
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void 
       for (int k = 0; k < KP; k += 4) {
         const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) h[k + t] = hv[t];
+        for (int t = 0; t < 4; ++t) h[k + t] = vn_uniform(hv[t]);      // (wave-uniform: scalar registers)
       }
       f32x4 vb[NCH], x2[NCH], a1[NCH], a2[NCH];
       float vbx, x2x, a1x = 0.f, a2x = 0.f;
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void 
     for (int k = 0; k < KP; k += 4) {
       const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) h[k + t] = hv[t];
+      for (int t = 0; t < 4; ++t) h[k + t] = vn_uniform(hv[t]);
     }
     f32x4 vb[NCH], x2[NCH], a1[NCH], a2[NCH];
     float vbx, x2x, a1x = 0.f, a2x = 0.f;
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
   FrameCtx<NCH, KP, ST> fc(a, wlds + (KP <= 8 ? (size_t)(threadIdx.x >> 6) * a.Fs * KP : 0));
   fc.stage_block_w();
   // (two chunks, rank <= 16: 0.306 -> 0.286 ms on the 1024-pt shape; at rank 32 the registers do not suffice: 0.535 -> 0.608)
-  using RBt = RowBatch<NCH, ST, 1, RT, (VN_HG_FULL2 && sizeof(ST) == 2 && NCH == 2 && KP <= 16) ? 32 : 0>;
+  using RBt = RowBatch<NCH, ST, 1, RT, (VN_HG_FULL2 && sizeof(ST) == 2 && NCH == 2 && KP <= VN_HG_FULL2_KMAX) ? 32 : 0>;
   int n_beg, n_end;
   wave_frames(a.NT, n_beg, n_end);
 #if VN_HG_STAGGER > 0
@@ -580,7 +585,9 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
     if (!a.gains_only) {
       // ---- H update (mcem.py:118-121): W already updated and normalised; H carries the pending column norms
 #pragma unroll
-      for (int k = 0; k < KP; ++k) hs[k] *= fc.nwk(k);
+      // (wave-uniform values, moved to the scalar registers: KP vector registers each for the old and the new activations
+      // otherwise -- 64 of them at rank 32, which is what kept a whole frame's rows from fitting beside them)
+      for (int k = 0; k < KP; ++k) hs[k] = vn_uniform(hs[k] * fc.nwk(k));
       fc.noise_var(utt, hs, vb, vbx);
       f32x4 a1[NCH], a2[NCH];
       float a1x = 0.f, a2x = 0.f;
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void 
         fc.w_dot(utt, k, a2, a1, a2x, a1x, nu, de);
         nu = wave_sum(nu);
         de = wave_sum(de);
-        hn[k] = k < a.K ? hs[k] * __builtin_amdgcn_sqrtf(nu * fast_rcp(de)) : 0.f;       // mcem.py:121
+        hn[k] = vn_uniform(k < a.K ? hs[k] * __builtin_amdgcn_sqrtf(nu * fast_rcp(de)) : 0.f);       // mcem.py:121
       }
       if (fc.lane == 0) {
 #pragma unroll
@@ -759,7 +766,7 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void 
       for (int k = 0; k < KP; k += 4) {
         const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) h[k + t] = hv[t];
+        for (int t = 0; t < 4; ++t) h[k + t] = vn_uniform(hv[t]);      // (wave-uniform: scalar registers)
       }
       fc.noise_var(utt, h, vb, vbx);
     }
