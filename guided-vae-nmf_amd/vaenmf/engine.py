@@ -187,7 +187,9 @@ class BatchEngine:
         if self.Dy == 0:
             raise ValueError("decoder has no label input")
         y = y.to(self.device, torch.float32).contiguous()
-        self.B1 = torch.empty(self.NT, HID, device=self.device, dtype=torch.float32)
+        if getattr(self, "_bB1", None) is None:           # fixed address from batch to batch (vaenmf_em_run's graph signature)
+            self._bB1 = torch.empty(self._max_frames, HID, device=self.device, dtype=torch.float32)
+        self.B1 = self._bB1[:self.NT]
         check(lib().vaenmf_layer1_bias(self._plan, _ptr(y), self.Dy, _ptr(self.B1), _stream()))
 
     # ------------------------------------------------------------------ hot path
