@@ -90,6 +90,12 @@ struct vaenmf_plan {
   std::vector<std::vector<uint64_t>> g_seen;   // signatures run eagerly once (a signature is captured at its second appearance)
   uint64_t g_tick = 0;
   bool g_off = false;                   // capture failed once on this plan: stay eager
+  // vaenmf_bind_batch_async: the per-batch seeds go up from a ring of pinned slots (a slot is reused when its copy is done)
+  static constexpr int SEED_RING = 8;
+  uint64_t* h_seed_ring = nullptr;      // pinned [SEED_RING][max_utts]
+  hipEvent_t seed_ev[SEED_RING] = {};
+  bool seed_ev_used[SEED_RING] = {};
+  int seed_pos = 0;
   int last_em_graph = 0;                // VAENMF_Q_EM_GRAPH: 1 when the last vaenmf_em_run was a graph launch
 };
 

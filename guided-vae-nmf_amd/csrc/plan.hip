@@ -9,6 +9,7 @@
 #include <set>
 #include <utility>
 #include "common.h"
+#include <algorithm>
 
 static thread_local char g_err[512] = "";
 
@@ -167,6 +168,8 @@ extern "C" void vaenmf_plan_destroy(vaenmf_plan* p) {
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
   for (auto& gph : p->g_cache) if (gph.exec) (void)hipGraphExecDestroy(gph.exec);
   if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
+  if (p->h_seed_ring) (void)hipHostFree(p->h_seed_ring);
+  for (int i = 0; i < vaenmf_plan::SEED_RING; ++i) if (p->seed_ev[i]) (void)hipEventDestroy(p->seed_ev[i]);
   delete p;
 }
 
@@ -244,53 +247,78 @@ extern "C" int vaenmf_set_decoder_weights(vaenmf_plan* p, const float* W1, int32
   return 0;
 }
 
-extern "C" int vaenmf_bind_batch(vaenmf_plan* p, int32_t n_utt, const int32_t* frame_offsets, const uint64_t* utt_seeds) {
+// Binds a batch.  The frame tables are rebuilt and uploaded (blocking copies) only when the batch's frame structure
+// differs from the bound one; the utterance seeds -- the only per-batch table of a job that repeats its batch shape -- go
+// up asynchronously on `stream` from a ring of pinned slots, so the call does not wait for the GPU and a caller that
+// never synchronises can prepare the next batch while this one runs.
+extern "C" int vaenmf_bind_batch_async(vaenmf_plan* p, int32_t n_utt, const int32_t* frame_offsets, const uint64_t* utt_seeds, void* stream) {
   VN_REQUIRE(p && frame_offsets, "null argument");
   VN_REQUIRE(n_utt >= 1 && n_utt <= p->cfg.max_utts, "n_utt=%d exceeds capacity %d", n_utt, p->cfg.max_utts);
   VN_REQUIRE(frame_offsets[0] == 0, "frame_offsets[0] must be 0");
   const int NT = frame_offsets[n_utt];
   VN_REQUIRE(NT >= 1 && NT <= p->cfg.max_frames, "total frames %d exceeds capacity %d", NT, p->cfg.max_frames);
-  std::vector<int32_t> t_utt, t_n0, t_cnt, f_utt(NT), f_loc(NT);
-  for (int u = 0; u < n_utt; ++u) {
-    const int b = frame_offsets[u], e = frame_offsets[u + 1];
-    VN_REQUIRE(e > b, "utterance %d is empty", u);
-    for (int n = b; n < e; n += p->tile_frames) {
-      t_utt.push_back(u);
-      t_n0.push_back(n);
-      t_cnt.push_back(e - n < p->tile_frames ? e - n : p->tile_frames);
+  hipStream_t st = (hipStream_t)stream;
+  const bool same = p->NT == NT && p->n_utt == n_utt && (int)p->h_frame_off.size() == n_utt + 1 &&
+                    std::equal(p->h_frame_off.begin(), p->h_frame_off.end(), frame_offsets);
+  if (!same) {
+    std::vector<int32_t> t_utt, t_n0, t_cnt, f_utt(NT), f_loc(NT);
+    for (int u = 0; u < n_utt; ++u) {
+      const int b = frame_offsets[u], e = frame_offsets[u + 1];
+      VN_REQUIRE(e > b, "utterance %d is empty", u);
+      for (int n = b; n < e; n += p->tile_frames) {
+        t_utt.push_back(u);
+        t_n0.push_back(n);
+        t_cnt.push_back(e - n < p->tile_frames ? e - n : p->tile_frames);
+      }
+      for (int n = b; n < e; ++n) { f_utt[n] = u; f_loc[n] = n - b; }
     }
-    for (int n = b; n < e; ++n) { f_utt[n] = u; f_loc[n] = n - b; }
+    std::vector<int32_t> w_utt, w_n0, w_cnt;              // wave tiles of the wave-private chain (chain.hip)
+    for (int u = 0; u < n_utt; ++u)
+      for (int n = frame_offsets[u]; n < frame_offsets[u + 1]; n += 16) {
+        w_utt.push_back(u);
+        w_n0.push_back(n);
+        w_cnt.push_back(frame_offsets[u + 1] - n < 16 ? frame_offsets[u + 1] - n : 16);
+      }
+    VN_CHECK_HIP(hipStreamSynchronize(st));               // kernels of the previous batch may still read the tables
+    int e = 0;
+    e |= upload(p->d_frame_off, frame_offsets, (size_t)n_utt + 1);
+    e |= upload(p->d_tile_utt, t_utt.data(), t_utt.size());
+    e |= upload(p->d_tile_n0, t_n0.data(), t_n0.size());
+    e |= upload(p->d_tile_cnt, t_cnt.data(), t_cnt.size());
+    e |= upload(p->d_frame_utt, f_utt.data(), f_utt.size());
+    e |= upload(p->d_frame_loc, f_loc.data(), f_loc.size());
+    e |= upload(p->d_wt_utt, w_utt.data(), w_utt.size());
+    e |= upload(p->d_wt_n0, w_n0.data(), w_n0.size());
+    e |= upload(p->d_wt_cnt, w_cnt.data(), w_cnt.size());
+    if (e) return -2;
+    p->n_wtiles = (int)w_utt.size();
+    p->n_tiles = (int)t_utt.size();
+    p->n_utt = n_utt;
+    p->NT = NT;
+    p->h_frame_off.assign(frame_offsets, frame_offsets + n_utt + 1);
   }
-  std::vector<int32_t> w_utt, w_n0, w_cnt;              // wave tiles of the wave-private chain (chain.hip)
-  for (int u = 0; u < n_utt; ++u)
-    for (int n = frame_offsets[u]; n < frame_offsets[u + 1]; n += 16) {
-      w_utt.push_back(u);
-      w_n0.push_back(n);
-      w_cnt.push_back(frame_offsets[u + 1] - n < 16 ? frame_offsets[u + 1] - n : 16);
-    }
-  std::vector<uint64_t> seeds(n_utt);
+  // ---- seeds: pinned slot -> device, stream-ordered
+  if (!p->h_seed_ring) VN_CHECK_HIP(hipHostMalloc((void**)&p->h_seed_ring, (size_t)vaenmf_plan::SEED_RING * p->cfg.max_utts * sizeof(uint64_t), hipHostMallocDefault));
+  const int slot = p->seed_pos;
+  p->seed_pos = (p->seed_pos + 1) % vaenmf_plan::SEED_RING;
+  if (!p->seed_ev[slot]) VN_CHECK_HIP(hipEventCreateWithFlags(&p->seed_ev[slot], hipEventDisableTiming));
+  if (p->seed_ev_used[slot]) VN_CHECK_HIP(hipEventSynchronize(p->seed_ev[slot]));      // (eight binds ago: long done)
+  uint64_t* hs = p->h_seed_ring + (size_t)slot * p->cfg.max_utts;
   for (int u = 0; u < n_utt; ++u) {
     uint64_t x = 0x5EEDull + (uint64_t)u;
-    seeds[u] = utt_seeds ? utt_seeds[u] : splitmix64(x);
+    hs[u] = utt_seeds ? utt_seeds[u] : splitmix64(x);
   }
-  int e = 0;
-  e |= upload(p->d_frame_off, frame_offsets, (size_t)n_utt + 1);
-  e |= upload(p->d_tile_utt, t_utt.data(), t_utt.size());
-  e |= upload(p->d_tile_n0, t_n0.data(), t_n0.size());
-  e |= upload(p->d_tile_cnt, t_cnt.data(), t_cnt.size());
-  e |= upload(p->d_frame_utt, f_utt.data(), f_utt.size());
-  e |= upload(p->d_frame_loc, f_loc.data(), f_loc.size());
-  e |= upload(p->d_utt_seed, seeds.data(), seeds.size());
-  e |= upload(p->d_wt_utt, w_utt.data(), w_utt.size());
-  e |= upload(p->d_wt_n0, w_n0.data(), w_n0.size());
-  e |= upload(p->d_wt_cnt, w_cnt.data(), w_cnt.size());
-  if (e) return -2;
-  p->n_wtiles = (int)w_utt.size();
+  VN_CHECK_HIP(hipMemcpyAsync(p->d_utt_seed, hs, (size_t)n_utt * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  VN_CHECK_HIP(hipEventRecord(p->seed_ev[slot], st));
+  p->seed_ev_used[slot] = true;
   p->store_R = p->store_Rs = 0;                         // the store's contents belong to the previous batch
-  p->n_utt = n_utt;
-  p->NT = NT;
-  p->n_tiles = (int)t_utt.size();
-  p->h_frame_off.assign(frame_offsets, frame_offsets + n_utt + 1);
+  return 0;
+}
+
+// The blocking form: every table is on the device when the call returns.
+extern "C" int vaenmf_bind_batch(vaenmf_plan* p, int32_t n_utt, const int32_t* frame_offsets, const uint64_t* utt_seeds) {
+  if (int e = vaenmf_bind_batch_async(p, n_utt, frame_offsets, utt_seeds, nullptr)) return e;
+  VN_CHECK_HIP(hipStreamSynchronize(nullptr));
   return 0;
 }
 

@@ -83,7 +83,7 @@ class BatchEngine:
         sd = None
         if seeds is not None:
             sd = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64))
-        check(lib().vaenmf_bind_batch(self._plan, self.U, self.frame_off.ctypes.data, None if sd is None else sd.ctypes.data))
+        check(lib().vaenmf_bind_batch_async(self._plan, self.U, self.frame_off.ctypes.data, None if sd is None else sd.ctypes.data, _stream()))
         dev, f32 = self.device, torch.float32
         NT, Fs, Kp = self.NT, self.Fs, self.Kp
         # Device buffers are allocated once at the plan's capacity (max_frames, max_utts) and every bind takes leading
@@ -109,8 +109,16 @@ class BatchEngine:
             t.zero_()
         self.g.fill_(1.0)
         self.B1 = None
-        self.d_frame_off = torch.from_numpy(self.frame_off).to(dev)
-        self.d_frame_utt = torch.repeat_interleave(torch.arange(self.U, dtype=torch.int32), torch.tensor(fc)).to(dev)
+        # (device copies of the frame tables, cached by frame structure: an upload from pageable memory would make the host wait
+        # for the GPU every batch)
+        key = tuple(fc)
+        cache = self.__dict__.setdefault("_tab_cache", {})
+        if key not in cache:
+            if len(cache) >= 8:
+                cache.pop(next(iter(cache)))
+            cache[key] = (torch.from_numpy(self.frame_off.copy()).to(dev),
+                          torch.repeat_interleave(torch.arange(self.U, dtype=torch.int32), torch.tensor(fc)).to(dev))
+        self.d_frame_off, self.d_frame_utt = cache[key]
         return self
 
     def utt_slice(self, u):
@@ -146,13 +154,24 @@ class BatchEngine:
         check(lib().vaenmf_dense(_ptr(x), M, inn, x.stride(0), _ptr(w), _ptr(b), out, act, _ptr(y), out, _stream()))
         return y
 
+    def _dev(self, a):
+        """Device copy of a host weight array, uploaded once per array object (an upload from pageable memory per call
+        makes the host wait for the GPU)."""
+        cache = self.__dict__.setdefault("_w_cache", {})
+        ent = cache.get(id(a))
+        if ent is None or ent[0] is not a:
+            if len(cache) >= 64:
+                cache.clear()
+            ent = cache[id(a)] = (a, torch.from_numpy(_np32(a)).to(self.device))
+        return ent[1]
+
     def encode(self, enc, y=None):
         """Z = posterior mean of encoder(|X|^2 [cat y]) (mcem.py:367-368 / :214-215).
         enc = [(W,b)...hidden, (Wmu,bmu)] float32 numpy."""
         x = self.X2[:, :self.F]
         if y is not None:
             x = torch.cat([x, y], dim=1).contiguous()
-        t = lambda a: torch.from_numpy(_np32(a)).to(self.device)
+        t = self._dev
         h = x
         for (w, b) in enc[:-1]:
             h = self.dense(h, t(w), t(b), _lib.ACT_TANH)
@@ -164,18 +183,25 @@ class BatchEngine:
         normalisation of |X|^2 (folded into the first layer on the host), ReLU hidden layers,
         sigmoid output, hard threshold 0.5.  clf = [(W,b) hidden..., (W,b) output] float32 numpy;
         mean/std numpy (F,1).  Returns (y_soft, y_hard) device float32 [NT,Dy]."""
-        t = lambda a: torch.from_numpy(_np32(a)).to(self.device)
-        layers = [(np.asarray(w, np.float64), np.asarray(b, np.float64)) for w, b in clf]
-        if mean is not None:
-            m = np.asarray(mean, np.float64).reshape(-1)
-            s = np.asarray(std, np.float64).reshape(-1) + eps
-            w0, b0 = layers[0]
-            layers[0] = (w0 / s[None, :], b0 - (w0 / s[None, :]) @ m)
+        cache = self.__dict__.setdefault("_clf_cache", {})
+        ent = cache.get(id(clf))
+        if ent is None or ent[0] is not clf or ent[1] is not mean or ent[2] is not std:       # folded layers on the device, once per classifier
+            t = lambda a: torch.from_numpy(_np32(a)).to(self.device)
+            layers = [(np.asarray(w, np.float64), np.asarray(b, np.float64)) for w, b in clf]
+            if mean is not None:
+                m = np.asarray(mean, np.float64).reshape(-1)
+                s = np.asarray(std, np.float64).reshape(-1) + eps
+                w0, b0 = layers[0]
+                layers[0] = (w0 / s[None, :], b0 - (w0 / s[None, :]) @ m)
+            if len(cache) >= 8:
+                cache.clear()
+            ent = cache[id(clf)] = (clf, mean, std, [(t(w), t(b)) for w, b in layers])
+        dl = ent[3]
         h = self.X2[:, :self.F]
-        for (w, b) in layers[:-1]:
-            h = self.dense(h, t(w), t(b), _lib.ACT_RELU)
-        w, b = layers[-1]
-        return self.dense(h, t(w), t(b), _lib.ACT_SIGMOID), self.dense(h, t(w), t(b), _lib.ACT_STEP)
+        for (w, b) in dl[:-1]:
+            h = self.dense(h, w, b, _lib.ACT_RELU)
+        w, b = dl[-1]
+        return self.dense(h, w, b, _lib.ACT_SIGMOID), self.dense(h, w, b, _lib.ACT_STEP)
 
     def set_noise_psd(self, Vb):
         """Fixed noise variance (the *_noNMF variants, mcem.py:493-760): Vb device float32 [NT,Fs] or None."""

@@ -24,13 +24,27 @@ def ratios_from_gram(G):
     return 10 * np.log10(e_t / e_r), 10 * np.log10(e_t / e_n), 10 * np.log10(e_t / e_a)
 
 
-def gram3_batch(s_hat, s, n, sample_counts):
-    """Device float32 [sum T] x3 -> numpy float64 [U,6]."""
+_SOFF = {}
+
+
+def gram3_batch_device(s_hat, s, n, sample_counts):
+    """Device float32 [sum T] x3 -> DEVICE float64 [U,6] (no synchronisation: a job can collect the Gram sums of many
+    batches and read them back once)."""
     dev = s_hat.device
-    soff = torch.tensor(np.concatenate([[0], np.cumsum(sample_counts)]), dtype=torch.int64, device=dev)
+    key = (tuple(int(t) for t in sample_counts), str(dev))
+    soff = _SOFF.get(key)
+    if soff is None:
+        if len(_SOFF) >= 16:
+            _SOFF.pop(next(iter(_SOFF)))
+        soff = _SOFF[key] = torch.tensor(np.concatenate([[0], np.cumsum(sample_counts)]), dtype=torch.int64, device=dev)
     out = torch.empty(len(sample_counts), 6, device=dev, dtype=torch.float64)
     check(lib().vaenmf_gram3_batch(_ptr(s_hat), _ptr(s), _ptr(n), len(sample_counts), _ptr(soff), _ptr(out), _stream()))
-    return out.cpu().numpy()
+    return out
+
+
+def gram3_batch(s_hat, s, n, sample_counts):
+    """Device float32 [sum T] x3 -> numpy float64 [U,6]."""
+    return gram3_batch_device(s_hat, s, n, sample_counts).cpu().numpy()
 
 
 def energy_ratios(s_hat, s, n):

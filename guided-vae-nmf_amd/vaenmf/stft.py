@@ -23,18 +23,33 @@ def frame_geometry(n_samples, fs, wlen_sec, hop_percent):
     return nfft.value, hop.value, nfr.value, npad.value
 
 
+_TABLES = {}
+
+
+def _remember(key, tab, limit=16):
+    if len(_TABLES) >= limit:
+        _TABLES.pop(next(iter(_TABLES)))
+    _TABLES[key] = tab
+
+
 def stft_batch(wav, sample_counts, fs, wlen_sec, hop_percent, Fs=None, device="cuda:0"):
     """wav: device float32 [sum T] (utterances concatenated).  Returns (X [NT,Fs,2], frame_counts)."""
-    geo = [frame_geometry(t, fs, wlen_sec, hop_percent) for t in sample_counts]
-    nfft, hop = geo[0][0], geo[0][1]
+    dev = torch.device(device)
+    key = ("stft", tuple(int(t) for t in sample_counts), fs, wlen_sec, hop_percent, str(dev))
+    tab = _TABLES.get(key)
+    if tab is None:       # index tables on the device, cached per batch shape (pageable uploads make the host wait for the GPU)
+        geo = [frame_geometry(t, fs, wlen_sec, hop_percent) for t in sample_counts]
+        fc_ = [g[2] for g in geo]
+        tab = (geo[0][0], geo[0][1], fc_,
+               torch.tensor(np.concatenate([[0], np.cumsum(sample_counts)]), dtype=torch.int64, device=dev),
+               torch.tensor(np.concatenate([[0], np.cumsum(fc_)]), dtype=torch.int32, device=dev),
+               torch.repeat_interleave(torch.arange(len(fc_), dtype=torch.int32), torch.tensor(fc_)).to(dev),
+               torch.tensor([g[3] for g in geo], dtype=torch.int32, device=dev))
+        _remember(key, tab)
+    nfft, hop, fc, soff, foff, futt, plen = tab
+    fc = list(fc)
     F = nfft // 2 + 1
     Fs = Fs or (F + 15) // 16 * 16
-    fc = [g[2] for g in geo]
-    dev = torch.device(device)
-    soff = torch.tensor(np.concatenate([[0], np.cumsum(sample_counts)]), dtype=torch.int64, device=dev)
-    foff = torch.tensor(np.concatenate([[0], np.cumsum(fc)]), dtype=torch.int32, device=dev)
-    futt = torch.repeat_interleave(torch.arange(len(fc), dtype=torch.int32), torch.tensor(fc)).to(dev)
-    plen = torch.tensor([g[3] for g in geo], dtype=torch.int32, device=dev)
     NT = int(sum(fc))
     X = torch.empty(NT, Fs, 2, device=dev, dtype=torch.float32)
     check(lib().vaenmf_stft_batch(_ptr(wav), NT, _ptr(soff), _ptr(foff), _ptr(futt), _ptr(plen), nfft, hop, Fs, _ptr(X), _stream()))
@@ -44,8 +59,13 @@ def stft_batch(wav, sample_counts, fs, wlen_sec, hop_percent, Fs=None, device="c
 def istft_batch(S, frame_counts, sample_counts, nfft, hop, device="cuda:0"):
     """S: device [NT,Fs,2] complex64 -> device float32 [sum T] (max_len = sample_counts[u])."""
     dev = torch.device(device)
-    soff = torch.tensor(np.concatenate([[0], np.cumsum(sample_counts)]), dtype=torch.int64, device=dev)
-    foff = torch.tensor(np.concatenate([[0], np.cumsum(frame_counts)]), dtype=torch.int32, device=dev)
+    key = ("istft", tuple(int(t) for t in sample_counts), tuple(int(t) for t in frame_counts), str(dev))
+    tab = _TABLES.get(key)
+    if tab is None:
+        tab = (torch.tensor(np.concatenate([[0], np.cumsum(sample_counts)]), dtype=torch.int64, device=dev),
+               torch.tensor(np.concatenate([[0], np.cumsum(frame_counts)]), dtype=torch.int32, device=dev))
+        _remember(key, tab)
+    soff, foff = tab
     NT, Fs = S.shape[0], S.shape[1]
     work = torch.empty(NT, nfft, device=dev, dtype=torch.float32)
     out = torch.empty(int(sum(sample_counts)), device=dev, dtype=torch.float32)

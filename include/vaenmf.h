@@ -96,6 +96,12 @@ int vaenmf_set_decoder_weights(vaenmf_plan* p, const float* W1, int32_t in1, con
  * depend on how utterances are batched). */
 int vaenmf_bind_batch(vaenmf_plan* p, int32_t n_utt, const int32_t* frame_offsets,
                       const uint64_t* utt_seeds);
+/* The same without waiting for the GPU when the batch's frame structure repeats the bound one:
+ * the frame tables stay, the seeds go up stream-ordered from pinned memory.  A caller that never
+ * synchronises (results collected later) can prepare batch k+1 while batch k runs.  A batch with
+ * another frame structure synchronises `stream` and uploads the tables as vaenmf_bind_batch does. */
+int vaenmf_bind_batch_async(vaenmf_plan* p, int32_t n_utt, const int32_t* frame_offsets,
+                            const uint64_t* utt_seeds, void* stream);
 
 /* B1[n][h] = b1[h] + sum_d W1[h][L+d] * y[n][d]   (label half of mcem.py:242/261/283).
  * y DEV [NT][Dy]. */
