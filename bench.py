@@ -41,7 +41,7 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)     # (eager call, then the graph capture: both outside the timed steps)
     ap.add_argument("--utts", type=int, default=BATCH, help="utterances per batch (N=1 default workload: one batch per step)")
     ap.add_argument("--total-utts", type=int, default=0,
                     help="fixed utterance set sharded over the ranks (strong scaling; default 1000 when --gpus > 1)")
