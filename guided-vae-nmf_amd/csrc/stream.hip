@@ -33,6 +33,9 @@
 #ifndef VN_HG_FULL2
 #define VN_HG_FULL2 1
 #endif
+#ifndef VN_HG_FULLF
+#define VN_HG_FULLF 1
+#endif
 #ifndef VN_HG_FULL2_KMAX
 #define VN_HG_FULL2_KMAX 16     // (rank 32: the whole-frame batch still spills, 288 bytes, and gains nothing)
 #endif
@@ -536,12 +539,14 @@ __global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_WS_WAVES : 2) void 
 
 // RT > 0: exactly RT samples per frame (no per-row branch: 90 uniform branches per frame otherwise)
 template <int NCH, int KP, typename ST, int RT = 0>
-__global__ __launch_bounds__(256, (KP <= 8 && NCH == 1) ? VN_HG_WAVES : 2) void hg_stream_kernel(const StreamArgs a) {
+__global__ __launch_bounds__(256, (KP <= 8 && NCH == 1 && !(VN_HG_FULLF && sizeof(ST) == 4)) ? VN_HG_WAVES : 2) void hg_stream_kernel(const StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   FrameCtx<NCH, KP, ST> fc(a, wlds + (KP <= 8 ? (size_t)(threadIdx.x >> 6) * a.Fs * KP : 0));
   fc.stage_block_w();
   // (two chunks, rank <= 16: 0.306 -> 0.286 ms on the 1024-pt shape; at rank 32 the registers do not suffice: 0.535 -> 0.608)
-  using RBt = RowBatch<NCH, ST, 1, RT, (VN_HG_FULL2 && sizeof(ST) == 2 && NCH == 2 && KP <= VN_HG_FULL2_KMAX) ? 32 : 0>;
+  // float rows (bf16x3 mode), one chunk: 32 rows x 4 registers at two wavefronts per SIMD hold the whole frame as well (16 per
+  // batch re-read both batches in every pass: 3x the traffic of a kernel that is memory-bound with float rows)
+  using RBt = RowBatch<NCH, ST, 1, RT, ((VN_HG_FULL2 && sizeof(ST) == 2 && NCH == 2 && KP <= VN_HG_FULL2_KMAX) || (VN_HG_FULLF && sizeof(ST) == 4 && NCH == 1 && KP <= 8)) ? 32 : 0>;
   int n_beg, n_end;
   wave_frames(a.NT, n_beg, n_end);
 #if VN_HG_STAGGER > 0
