@@ -1138,7 +1138,7 @@ int launch_st(StreamArgs a, int grid, hipStream_t st) {
   }
   if (KIND == SK_WSTATS) hipLaunchKernelGGL((wstats_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
   else if (KIND == SK_HG) {
-    constexpr int RBm = RowBatch<NCH, ST>::RB;
+    constexpr int RBm = (VN_HG_FULLF && sizeof(ST) == 4 && NCH == 1 && KP <= 8) ? 32 : RowBatch<NCH, ST>::RB;     // (as hg_stream_kernel's RBt)
     if (VN_HG_EXACT && NCH == 1 && KP <= 8 && a.R == 30 && RBm >= 30) {
       if (int e = vn_ensure_dyn_lds((const void*)hg_stream_kernel<NCH, KP, ST, (RBm >= 30 && NCH == 1 ? 30 : 0)>, 80 * 1024)) return e;
       hipLaunchKernelGGL((hg_stream_kernel<NCH, KP, ST, (RBm >= 30 && NCH == 1 ? 30 : 0)>), dim3(grid), dim3(256), lds, st, a);
