@@ -74,15 +74,36 @@ def spawn_ranks(args):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), VAENMF_BENCH_CHILD="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))     # fresh children, no re-exec
+    # Poll all ranks together: the first rank that exits non-zero, or a rank still running at the wall-clock limit, takes
+    # the others down with it (they would otherwise sit in init_process_group / all_reduce until the collective's own
+    # timeout, 10-30 minutes) and the launcher returns non-zero -- never a half-reported run.
+    limit = float(os.environ.get("VAENMF_BENCH_RANK_TIMEOUT", "1500"))
+    t0 = time.monotonic()
     rc = 0
+    while rc == 0:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc = bad[0][1] if bad[0][1] > 0 else 1
+            print("[bench] rank %d exited with code %d: stopping the other ranks" % bad[0], file=sys.stderr, flush=True)
+        elif all(c == 0 for c in codes):
+            return 0
+        elif time.monotonic() - t0 > limit:
+            rc = 124
+            print("[bench] ranks still running after %.0f s: stopping them" % limit, file=sys.stderr, flush=True)
+        else:
+            time.sleep(0.05)
+    for p in procs:                                     # exactly the processes started above
+        if p.poll() is None:
+            p.terminate()
+    t1 = time.monotonic()
     for p in procs:
-        p.wait()
-        rc = rc or p.returncode
-    if rc:                                              # a failed rank must never leave a half-reported run behind
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+        try:
+            p.wait(timeout=max(0.1, 5.0 - (time.monotonic() - t1)))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
     return rc
 
 
@@ -141,6 +162,11 @@ def main():
         raise SystemExit("bench.py: --gpus %d disagrees with WORLD_SIZE=%d" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    fault = os.environ.get("VAENMF_BENCH_TEST_FAULT", "")          # launcher tests: "<rank>:exit3" / "<rank>:hang", before any collective
+    if fault and int(fault.split(":")[0]) == rank:
+        if fault.endswith("exit3"):
+            sys.exit(3)
+        time.sleep(3600)
 
     import numpy as np
     import torch

@@ -2,6 +2,8 @@
 // dense layers (encoder / classifier), |X|^2, STFT / iSTFT, SI-SDR Gram sums.
 #include "common.h"
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4p;
+
 namespace {
 
 // ----------------------------------------------------------------------------
@@ -304,6 +306,27 @@ __global__ __launch_bounds__(256) void gram3_kernel(const float* __restrict__ sh
   if (threadIdx.x < 6) out[(size_t)u * 6 + threadIdx.x] = red[threadIdx.x][0];
 }
 
+
+// HBM read probe (bench.py's measured ceiling for the streaming M-step kernels): every lane keeps UNR 16-byte loads in
+// flight, a workgroup sweeps contiguous 4 KB pieces in a grid-stride loop, the grid is the resident set (8 workgroups of
+// 256 threads per CU = 8 wavefronts per SIMD).  The loaded words are folded into one value per lane that is stored only
+// if it equals a sentinel the data never produces, so nothing is written and nothing is optimised away.
+template <int UNR>
+__global__ __launch_bounds__(256) void hbm_read_probe_kernel(const u32x4p* __restrict__ buf, size_t n16, unsigned* sink) {
+  const size_t stride = (size_t)gridDim.x * 256 * UNR;
+  unsigned acc = 0;
+  size_t i = (size_t)blockIdx.x * 256 * UNR + threadIdx.x;
+  for (; i + (size_t)(UNR - 1) * 256 < n16; i += stride) {
+    u32x4p v[UNR];
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) v[k] = __builtin_nontemporal_load(buf + i + (size_t)k * 256);
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) acc ^= v[k][0] ^ v[k][1] ^ v[k][2] ^ v[k][3];
+  }
+  for (; i < n16; i += 256) { const u32x4p v = buf[i]; acc ^= v[0] ^ v[1] ^ v[2] ^ v[3]; }
+  if (acc == 0x9E3779B9u) sink[0] = acc;
+}
+
 int ilog2(int n) { int b = 0; while ((1 << b) < n) ++b; return b; }
 
 }  // namespace
@@ -392,5 +415,34 @@ extern "C" int vaenmf_gram3_batch(const float* s_hat, const float* s, const floa
   VN_REQUIRE(s_hat && s && n && out && n_utt > 0, "vaenmf_gram3_batch: bad arguments");
   hipLaunchKernelGGL(gram3_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, s_hat, s, n, sample_offsets, out);
   VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// Measurement aid of bench.py (not on the hot path): the rate at which this GPU delivers a plain streaming read of `bytes`
+// bytes of `buf` (DEV, 16-byte aligned) to a hand-written kernel -- 16 bytes per lane, 8 wavefronts per SIMD, 4 loads in
+// flight per lane.  `reps` timed sweeps after one untimed sweep, HIP events on `stream`; synchronises.  sink DEV: 4 bytes.
+extern "C" int vaenmf_hbm_read_probe(const void* buf, int64_t bytes, int32_t reps, void* sink, double* gbps_out, void* stream) {
+  VN_REQUIRE(buf && sink && gbps_out && bytes >= (1 << 20) && reps > 0, "vaenmf_hbm_read_probe: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int dev = 0, cus = 256;
+  VN_CHECK_HIP(hipGetDevice(&dev));
+  VN_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  hipEvent_t e0, e1;
+  VN_CHECK_HIP(hipEventCreate(&e0));
+  VN_CHECK_HIP(hipEventCreate(&e1));
+  const size_t n16 = (size_t)bytes / 16;
+  auto sweep = [&]() { hipLaunchKernelGGL((hbm_read_probe_kernel<4>), dim3(cus * 8), dim3(256), 0, st, reinterpret_cast<const u32x4p*>(buf), n16, reinterpret_cast<unsigned*>(sink)); };
+  sweep();
+  (void)hipEventRecord(e0, st);
+  for (int r = 0; r < reps; ++r) sweep();
+  (void)hipEventRecord(e1, st);
+  hipError_t e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  VN_CHECK_HIP(e);
+  VN_CHECK_HIP(hipGetLastError());
+  *gbps_out = (double)(n16 * 16) * reps / ((double)ms * 1e-3) / 1e9;
   return 0;
 }

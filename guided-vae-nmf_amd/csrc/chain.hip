@@ -639,7 +639,26 @@ bool vn_wchain_supported(const vaenmf_plan* p) {
   return !(e && e[0] == '1');
 }
 
+// The wave chain addresses every per-frame buffer through a buffer resource with a 32-bit byte offset per lane and marks
+// idle lanes with WC_OOB: each buffer must end below it (with a margin for the per-step / per-tile immediate offsets).
+// Larger batches run the team kernel of engine.hip (64-bit addresses).
+extern "C" int vaenmf_wchain_addressable(int64_t NT, int32_t Rcap, int32_t steps, int32_t Fs, int32_t Kp, int32_t n_utt, int32_t replay) {
+  const uint64_t lim = 0xE0000000ull;
+  const uint64_t nt = (uint64_t)(NT > 0 ? NT : 0), S = (uint64_t)(steps > 0 ? steps : 0);
+  if (nt * (uint64_t)Rcap * LAT * 4 >= lim) return 0;                  // Zs
+  if (nt * (uint64_t)Fs * 4 >= lim) return 0;                          // X2, Vb
+  if ((uint64_t)n_utt * (uint64_t)Fs * (uint64_t)Kp * 4 >= lim) return 0;   // W
+  if (nt * (uint64_t)Kp * 4 >= lim) return 0;                          // Ht
+  if (nt * S * 4 >= lim) return 0;                                     // acc_out, u
+  if (replay && nt * S * LAT * 4 >= lim) return 0;                     // eps
+  return 1;
+}
+bool vn_wchain_fits(const vaenmf_plan* p, const VnChainCall& cc) {
+  return vaenmf_wchain_addressable(p->NT, cc.Rcap, cc.nsamples + cc.burnin, p->Fs, p->Kp, p->n_utt, cc.eps != nullptr) != 0;
+}
+
 int vn_launch_wchain(vaenmf_plan* p, const VnChainCall& cc, hipStream_t st) {
+  VN_REQUIRE(vn_wchain_fits(p, cc), "wave chain: a buffer of this batch (%d frames) passes the kernel's 32-bit byte offsets", p->NT);
   const bool split = p->cfg.precision == VAENMF_PREC_BF16X3;
   WcArgs a = {};
   a.w1f = p->w1f; a.w2f = p->w2f; a.w3f = p->w3c; a.b1 = p->b1; a.b2 = p->b2; a.b3 = p->b3c;

@@ -1387,6 +1387,7 @@ int check_bound(const vaenmf_plan* p) {
 
 // chain.hip
 bool vn_wchain_supported(const vaenmf_plan* p);
+bool vn_wchain_fits(const vaenmf_plan* p, const VnChainCall& cc);
 int vn_launch_wchain(vaenmf_plan* p, const VnChainCall& cc, hipStream_t st);
 // aux.hip
 int vn_launch_w_update(const vaenmf_plan* p, float* W, const float* Ht, hipStream_t st);
@@ -1421,12 +1422,14 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
     a.VsS = p->VsS; a.src = p->src; a.Rs = Rs;
     vss_bytes = need_v;
   }
-  if (vn_wchain_supported(p)) {                         // wave-private chains (chain.hip)
-    VnChainCall cc = {};
-    cc.X2 = X2; cc.W = W; cc.Ht = Ht; cc.g = g; cc.B1 = B1; cc.Z = Z; cc.Zs = Zs; cc.acc_out = acc_out;
-    cc.eps = rng->eps; cc.u = rng->u; cc.VsS = a.VsS; cc.VsS_bytes = vss_bytes; cc.src = a.src; cc.Rs = a.Rs;
-    cc.Rcap = Rcap; cc.nsamples = nsamples; cc.burnin = burnin; cc.rng_mode = rng->mode; cc.update_Z = update_Z;
-    cc.call = rng->call; cc.sd = a.sd;
+  VnChainCall cc = {};
+  cc.X2 = X2; cc.W = W; cc.Ht = Ht; cc.g = g; cc.B1 = B1; cc.Z = Z; cc.Zs = Zs; cc.acc_out = acc_out;
+  cc.eps = rng->eps; cc.u = rng->u; cc.VsS = a.VsS; cc.VsS_bytes = vss_bytes; cc.src = a.src; cc.Rs = a.Rs;
+  cc.Rcap = Rcap; cc.nsamples = nsamples; cc.burnin = burnin; cc.rng_mode = rng->mode; cc.update_Z = update_Z;
+  cc.call = rng->call; cc.sd = a.sd;
+  // wave-private chains (chain.hip) while every buffer of the batch is within their 32-bit byte offsets; a larger batch
+  // (about 300 k frames at 105 samples) runs the team kernel below, which addresses with 64 bits
+  if (vn_wchain_supported(p) && vn_wchain_fits(p, cc)) {
     ProfScope ps(p, VN_K_CHAIN, st);
     if (int e = vn_launch_wchain(p, cc, st)) return e;
     if (p->store_on) { p->store_R = nsamples; p->store_Rs = nsamples + 1; }

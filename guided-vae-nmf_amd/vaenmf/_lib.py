@@ -58,6 +58,8 @@ SIGNATURES = {
     "vaenmf_gram3_batch": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "vaenmf_profile_enable": (_I, [_P, _I]),
     "vaenmf_profile_read": (_I, [_P, _P, _P]),
+    "vaenmf_wchain_addressable": (_I, [_I64, _I, _I, _I, _I, _I, _I]),
+    "vaenmf_hbm_read_probe": (_I, [_P, _I64, _I, _P, C.POINTER(_D), _P]),
 }
 
 _lib = None

@@ -119,6 +119,6 @@ def allreduce_stats(stats, device):
     'nccl'); the only collective of the whole job."""
     import torch.distributed as dist
     t = torch.as_tensor(stats, dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():          # (also with one rank: the same call path as the N-rank job)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()

@@ -123,6 +123,11 @@ int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, const float
                     int32_t nsamples, int32_t burnin, float var_rw,
                     const vaenmf_rng* rng, float* acc_out, void* stream);
 
+/* 1 when the wave-private chain kernel (32-bit buffer offsets per lane) can address every buffer of a batch of NT frames
+ * (Zs [NT][Rcap][L], the replay draws [steps][NT][L], X2 [NT][Fs], W [n_utt][Fs][Kp], ...), 0 when vaenmf_mh_chain runs
+ * the 64-bit team kernel for it instead.  Pure host arithmetic (no GPU needed). */
+int vaenmf_wchain_addressable(int64_t NT, int32_t Rcap, int32_t steps, int32_t Fs, int32_t Kp, int32_t n_utt, int32_t replay);
+
 /* The draws the DEVICE generator hands to step s of chain invocation rng->call:
  * eps_out DEV [S][NT][L], u_out DEV [S][NT].  Test/debug aid: a REPLAY run fed with
  * these buffers is bit-identical to the DEVICE run. */
@@ -282,6 +287,12 @@ int vaenmf_gram3_batch(const float* s_hat, const float* s, const float* n, int32
  * kind (arrays of 5) and resets. */
 int vaenmf_profile_enable(vaenmf_plan* p, int32_t max_launches);
 int vaenmf_profile_read(vaenmf_plan* p, double* ms, int64_t* counts);
+
+/* Measurement aid of bench.py (no reference counterpart; not on the hot path): the rate in GB/s at which the GPU delivers
+ * a plain streaming read of `bytes` bytes of buf (DEV, 16-byte aligned) to a hand-written kernel (16 bytes per lane, 8
+ * wavefronts per SIMD, grid = resident set) -- the measured ceiling the streaming M-step kernels are compared with.
+ * `reps` timed sweeps after one untimed one; sink DEV (4 bytes, never written in practice).  Synchronises the stream. */
+int vaenmf_hbm_read_probe(const void* buf, int64_t bytes, int32_t reps, void* sink, double* gbps_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Reference-generated outcome distributions at the BENCH configurations (tests/test_gpu_statistical.py).
+
+Like make_si_sdr_dist.py this script IMPORTS THE REFERENCE (python.models.mcem.MCEM_M1, python.models.models.
+VariationalAutoencoder, python.metrics.energy_ratios -- build container only, it never travels) and runs its unmodified
+EM over 8 short synthetic utterances x S seeds of torch's global generator, with the oracle's STFT / iSTFT around it (the
+reference's own front end needs librosa).  Committed output: data only.  One process per (utterance, seed) task, one
+torch thread each (the tensors are tiny), so that the fixtures of round 3 -- about 6 000 reference runs -- fit a few
+hours of this container's 8 cores:
+
+  si_sdr_dist_n100.npz       F=257, K=8,  niter=100   BASELINE config 2 at its own iteration count      8 x 96 seeds
+  si_sdr_dist_f513k10.npz    F=513, K=10, niter=100   the reference scripts' own shape (evaluate_M1.py:77-92) 8 x 64
+  si_sdr_dist_f513k32.npz    F=513, K=32, niter=100   the stress rank of BASELINE config 5               8 x 48
+  si_sdr_dist_ext.npz        F=257, K=8,  niter=20    seeds 192..575 on top of si_sdr_dist.npz (same seeding rule):
+                                                      576 seeds per utterance bring 3 sigma of the combined spread
+                                                      of reference and GPU under 0.01 dB
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_si_sdr_dist_cfg.py <name>|all [procs]
+"""
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+
+CFG = {   # name: (F, K, niter, wlen, first seed, seeds)
+    "si_sdr_dist_n100": (257, 8, 100, 32e-3, 0, 96),
+    "si_sdr_dist_f513k10": (513, 10, 100, 64e-3, 0, 64),
+    "si_sdr_dist_f513k32": (513, 32, 100, 64e-3, 0, 48),
+    "si_sdr_dist_ext": (257, 8, 20, 32e-3, 192, 384),
+}
+UTTS, FS, T = 8, 16000, 16000
+_state = {}
+
+
+def _setup(F, wlen):
+    sys.path.insert(0, "/root/reference")
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import vaenmf_oracle as orc
+    from python.models import models as ref_models
+    torch.set_num_threads(1)
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=0)
+    vae = ref_models.VariationalAutoencoder([F, 32, [128, 128]])
+    vae.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+    vae.eval()
+    for p in vae.parameters():
+        p.requires_grad = False
+    sig = [orc.synth_utterance(u, T) for u in range(UTTS)]
+    X = [orc.stft(sg[2], fs=FS, wlen_sec=wlen).T for sg in sig]      # (N, F) complex64, as evaluate_M1.py:119-127
+    _state[(F, wlen)] = (vae, sig, X)
+
+
+def task(a):
+    F, K, niter, wlen, u, sd = a
+    if (F, wlen) not in _state:
+        _setup(F, wlen)
+    import numpy as np
+    import torch
+    import vaenmf_oracle as orc
+    from python.models import mcem as ref_mcem
+    from python import metrics as ref_metrics
+    vae, sig, X = _state[(F, wlen)]
+    s, n, x, _ = sig[u]
+    torch.manual_seed(10000 * u + sd)                                 # the reference seeds the global generator (mcem.py:1-5)
+    m = ref_mcem.MCEM_M1(niter=niter, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25, burnin_WF=75, var_RW=0.01)
+    m.init_parameters(X=X[u], vae=vae, nmf_rank=K, eps=1e-8, device="cpu")
+    cost = m.run()
+    s_hat = orc.istft(m.S_hat, fs=FS, wlen_sec=wlen, max_len=len(x))
+    sdr, sir, sar = ref_metrics.energy_ratios(s_hat=s_hat.astype(np.float64), s=s, n=n)
+    return u, sd, (sdr, sir, sar, float(cost[-1]))
+
+
+def main():
+    import multiprocessing as mp
+    import numpy as np
+    names = list(CFG) if sys.argv[1] == "all" else sys.argv[1].split(",")
+    procs = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(procs) as pool:
+        for name in names:
+            F, K, niter, wlen, s0, S = CFG[name]
+            out = np.zeros((UTTS, S, 4))
+            t0 = time.time()
+            todo = [(F, K, niter, wlen, u, s0 + i) for i in range(S) for u in range(UTTS)]
+            for k, (u, sd, r) in enumerate(pool.imap_unordered(task, todo, chunksize=4)):
+                out[u, sd - s0] = r
+                if (k + 1) % 64 == 0:
+                    print("%s: %d / %d runs  [%.0f s]" % (name, k + 1, len(todo), time.time() - t0), flush=True)
+            sem = np.sqrt(np.sum(out[:, :, 0].var(1, ddof=1) / S)) / UTTS
+            print("%s: mean SI-SDR %.4f dB, s.e. of the mean (seed spread) %.4f dB, per-run std %.3f dB  [%.0f s]"
+                  % (name, out[:, :, 0].mean(), sem, np.sqrt(out[:, :, 0].var(1, ddof=1).mean()), time.time() - t0), flush=True)
+            np.savez(os.path.join(HERE, name + ".npz"), results=out, F=F, K=K, niter=niter, fs=FS, wlen=wlen, utts=UTTS, seeds=S,
+                     first_seed=s0, T=T, columns=np.array(["si_sdr_db", "si_sir_db", "si_sar_db", "final_cost"]))
+
+
+if __name__ == "__main__":
+    main()

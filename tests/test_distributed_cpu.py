@@ -102,3 +102,25 @@ def test_bench_refuses_a_world_size_that_disagrees():
 def test_bench_single_rank_dry_run():
     rc, out, err = _run_bench(["--dry-run"])
     assert rc == 0 and out[0]["n_gpus"] == 1 and out[0]["scaling"] == "weak" and out[0]["utterances_total"] == 64
+
+
+def test_launcher_fails_fast_when_a_rank_dies_before_the_collective():
+    """Rank 1 exits with code 3 before init_process_group: rank 0 would wait in the rendezvous for the collective's own
+    timeout (minutes); the launcher must notice the dead rank, stop rank 0 and return its code within seconds."""
+    import time
+    t0 = time.monotonic()
+    rc, out, err = _run_bench(["--gpus", "2", "--dry-run", "--backend", "gloo"], env={"VAENMF_BENCH_TEST_FAULT": "1:exit3"})
+    dt = time.monotonic() - t0
+    assert rc == 3 and not out, (rc, out, err[-1000:])
+    assert "rank 1 exited with code 3" in err
+    assert dt < 60, dt
+
+
+def test_launcher_wall_clock_limit_stops_a_hung_rank():
+    import time
+    t0 = time.monotonic()
+    rc, out, err = _run_bench(["--gpus", "2", "--dry-run", "--backend", "gloo"],
+                              env={"VAENMF_BENCH_TEST_FAULT": "0:hang", "VAENMF_BENCH_RANK_TIMEOUT": "20"})
+    dt = time.monotonic() - t0
+    assert rc == 124 and not out, (rc, out, err[-1000:])
+    assert dt < 90, dt

@@ -224,3 +224,20 @@ def test_nist_sphere_reader(tmp_path):
     open(p, "wb").write(sphere("01", "pcm,embedded-shorten-v2.00"))
     with pytest.raises(NotImplementedError):
         wavio.read(p)
+
+
+def test_wave_chain_addressability_guard():
+    """The wave-private chain kernel uses 32-bit byte offsets per lane (idle lanes: 0xF0000000); a batch whose Zs / replay
+    draws / spectrogram would pass them must run the 64-bit team kernel instead (vaenmf_mh_chain checks this function).
+    Pure host arithmetic: callable without a GPU."""
+    from vaenmf import _lib
+    f = _lib.lib().vaenmf_wchain_addressable
+    assert f(32064, 75, 105, 272, 8, 64, 0) == 1                        # BASELINE config 2
+    assert f(125 * 251, 75, 105, 528, 32, 125, 0) == 1                  # config 5 shard
+    # Zs [NT][Rcap][32] float: 0xE0000000 / (75 * 128) = 391 468 frames
+    assert f(391_000, 75, 105, 272, 8, 700, 0) == 1 and f(392_000, 75, 105, 272, 8, 700, 0) == 0
+    # replay draws [S][NT][32] float: 0xE0000000 / (105 * 128) = 279 620 frames
+    assert f(279_000, 75, 105, 272, 8, 500, 1) == 1 and f(280_000, 75, 105, 272, 8, 500, 1) == 0
+    assert f(280_000, 75, 105, 272, 8, 500, 0) == 1                     # the device generator needs no draw buffer
+    # spectrogram rows [NT][Fs] float at the widest supported row
+    assert f(1_400_000, 1, 2, 640, 8, 2000, 0) == 1 and f(1_500_000, 1, 2, 640, 8, 2000, 0) == 0
