@@ -52,6 +52,7 @@ def parse_args(argv=None):
                     help="decoder MFMA mode: bf16 (BASELINE config 2) or bf16x3 (3-term split, ~fp32 accuracy)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra bf16x3 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-slice-utts", type=int, default=16, help="utterances of the config-4 slice of the CPU baseline (0: skip)")
     ap.add_argument("--no-configs", action="store_true", help="skip the one-step measurements of the other BASELINE configs")
     ap.add_argument("--force-store", action="store_true", help="sample store also in bf16x3 mode (float rows)")
     ap.add_argument("--no-store", action="store_true",
@@ -121,10 +122,32 @@ def algorithmic(F, niter, nsE, nsW):
     return bytes_per_frame, flop_row
 
 
-def cpu_baseline(F, K, niter):
+def _cpu_utt(a):
+    """One utterance of the CPU baseline in a worker process (one torch thread): seconds of TorchMCEM.run()."""
+    u, F, K, niter = a
+    import torch
+    torch.set_num_threads(1)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vaenmf_oracle as orc
+    import vaenmf_torch_cpu as tc
+    from vaenmf.synth import synth_utterance
+    s, n, x, _ = synth_utterance(u)
+    X = orc.stft(x, fs=16000, wlen_sec=32e-3 if F == 257 else 64e-3, hop_percent=0.25).T
+    m = tc.TorchMCEM("M1", niter)
+    m.init_parameters(X, orc.xavier_normal_params([F, 32, [128, 128]], seed=0), K, 1e-8, tc.TorchDraws(u))
+    t0 = time.perf_counter()
+    m.run()
+    return X.shape[0], time.perf_counter() - t0
+
+
+def cpu_baseline(F, K, niter, slice_utts=16):
     """The PyTorch-CPU restatement of EM.run (oracle/vaenmf_torch_cpu.py: float32 torch tensors, the reference's own
-    sequence of tensor operations, pinned by the reference-recorded golden runs) on BASELINE config 1: ONE 4 s
-    utterance, M1, `niter` EM iterations + Wiener chain, all host cores, median of 3 runs."""
+    sequence of tensor operations, pinned by the reference-recorded golden runs), on the host cores of this box:
+      (a) BASELINE config 1: ONE 4 s utterance, M1, `niter` EM iterations + Wiener chain, all threads on the one
+          utterance (the reference's single-process run), median of 3 runs;
+      (b) a 16-utterance slice of BASELINE config 4, run once: the utterances spread over a pool of
+          single-thread worker processes, the way the reference spreads utterances over processes
+          (scripts/evaluate_M1.py:203-216)."""
     import numpy as np
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -132,7 +155,8 @@ def cpu_baseline(F, K, niter):
     import vaenmf_torch_cpu as tc
     from vaenmf.synth import synth_utterance
     # the GPU box gives one GPU's job 16 host cores; more torch threads than that only add synchronisation time
-    threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = min(cores, 16)
     torch.set_num_threads(threads)
     s, n, x, _ = synth_utterance(0)
     X = orc.stft(x, fs=16000, wlen_sec=32e-3 if F == 257 else 64e-3, hop_percent=0.25).T
@@ -146,10 +170,26 @@ def cpu_baseline(F, K, niter):
         times.append(time.perf_counter() - t0)
         note("cpu baseline run %d: %.1f s" % (rep, times[-1]))
     t = sorted(times)[1]
-    return {"value": X.shape[0] / t, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "PyTorch-CPU restatement of EM.run (oracle/vaenmf_torch_cpu.py), BASELINE config 1: 1 utterance (%d frames, "
-                      "F=%d, K=%d), %d EM iterations + Wiener chain, torch.set_num_threads(%d), median of 3 runs "
-                      "(%.2f / %.2f / %.2f s)" % (X.shape[0], F, K, niter, threads, *sorted(times))}
+    out = {"value": X.shape[0] / t, "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": "PyTorch-CPU restatement of EM.run (oracle/vaenmf_torch_cpu.py), BASELINE config 1: 1 utterance (%d frames, "
+                     "F=%d, K=%d), %d EM iterations + Wiener chain, torch.set_num_threads(%d), median of 3 runs "
+                     "(%.2f / %.2f / %.2f s)" % (X.shape[0], F, K, niter, threads, *sorted(times))}
+    if slice_utts:
+        import multiprocessing as mp
+        nproc = min(threads, slice_utts)
+        t0 = time.perf_counter()
+        with mp.get_context("spawn").Pool(nproc) as pool:
+            pool.map(_cpu_utt, [(0, F, K, 1)] * nproc)                     # (workers up, torch imported: outside the clock)
+            t0 = time.perf_counter()
+            res = pool.map(_cpu_utt, [(u, F, K, niter) for u in range(slice_utts)], chunksize=1)
+            wall = time.perf_counter() - t0
+        frames = sum(r[0] for r in res)
+        note("cpu baseline, %d-utterance slice over %d single-thread workers: %.1f s" % (slice_utts, nproc, wall))
+        out["config4_slice"] = {"value": frames / wall, "unit": "frames/s", "cores": nproc, "kind": "port", "wall_s": wall,
+                                "sample": "%d utterances of BASELINE config 4 (%d frames, F=%d, K=%d, %d EM iterations + Wiener chain each), one "
+                                          "pass, %d single-thread worker processes in parallel (per-utterance run() %.1f-%.1f s)"
+                                          % (slice_utts, frames, F, K, niter, nproc, min(r[1] for r in res), max(r[1] for r in res))}
+    return out
 
 
 def main():
@@ -184,12 +224,18 @@ def main():
     comm_dev = torch.device("cpu") if (args.dry_run or args.backend == "gloo") else dev
     if not args.dry_run:
         torch.cuda.set_device(dev.index)
-    if world > 1:
+    # one rank under an external launcher (WORLD_SIZE=1 in the environment) may ask for the process group too
+    # (VAENMF_BENCH_FORCE_PG=1): the same RCCL path as the N-rank job, on one device
+    use_pg = world > 1 or (env_world is not None and os.environ.get("VAENMF_BENCH_FORCE_PG") == "1")
+    backend = None
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         if args.backend == "nccl" and not args.dry_run:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        backend = dist.get_backend()
 
     total = args.total_utts or (1000 if world > 1 else 0)
     strong = total > 0
@@ -202,7 +248,7 @@ def main():
     batches = [list(b) for b in np.array_split(np.asarray(ids, dtype=np.int64), nb)] if ids else []   # 125 -> 63 + 62
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         if not args.dry_run:
             torch.cuda.synchronize()
@@ -217,13 +263,13 @@ def main():
         barrier()
         tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
         cnt = torch.tensor([float(len(ids))], dtype=torch.float64)
-        if world > 1:
+        if use_pg:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "scaling": "strong" if strong else "weak", "utterances_total": int(cnt.item()),
                               "utterances_rank0": len(ids), "batches_rank0": [len(b) for b in batches], "stats_count": float(st[0, 0, 0])}))
-        if world > 1:
+        if use_pg:
             dist.destroy_process_group()
         return
 
@@ -302,7 +348,7 @@ def main():
     note("timed region: %.1f ms per step" % (dt / args.steps * 1e3))
     tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
     nutt = torch.tensor([float(len(ids))], dtype=torch.float64, device=comm_dev)
-    if world > 1:
+    if use_pg:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(nutt, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
@@ -310,19 +356,64 @@ def main():
     m_step_path = {1: "stored sample variances (rows written by the chain, streamed by the M-step and the Wiener filter)",
                    2: "decode (the M-step decodes the samples again)"}.get(_lib.lib().vaenmf_plan_query(rec.eng._plan, _lib.Q_MSTEP_PATH), "?")
 
-    # ---- one more step OUTSIDE the timed region with per-launch HIP events on the launch stream (vaenmf_profile_*):
-    # kernel breakdown and the dominant kernel's average launch time
-    n_launch = len(data) * (4 * args.niter + 8) + 16
-    _lib.check(_lib.lib().vaenmf_profile_enable(rec.eng._plan, n_launch))
-    step(args.warmup + args.steps)
-    ms = (C.c_double * 5)()
-    cn = (C.c_int64 * 5)()
-    _lib.check(_lib.lib().vaenmf_profile_read(rec.eng._plan, ms, cn))
-    _lib.check(_lib.lib().vaenmf_profile_enable(rec.eng._plan, 0))
+    lib = _lib.lib()
+    graph_flag = lambda r: int(lib.vaenmf_plan_query(r.eng._plan, _lib.Q_EM_GRAPH))
+    main_graph = graph_flag(rec)
+    KNAMES = ["mh_chain", "m_wstats", "w_update", "m_hg", "wiener"]
 
-    # ---- the other BASELINE configs, one timed step of one 64-utterance batch each (rank 0 of a 1-GPU run)
+    def profiled_step(r, c, dd, i, niter):
+        """One more step OUTSIDE any timed region with HIP events on the launch stream around every hot-path launch
+        (vaenmf_profile_*; launch by launch, the graph path is bypassed while profiling): per-kind ms and launch counts."""
+        _lib.check(lib.vaenmf_profile_enable(r.eng._plan, len(dd) * (4 * niter + 8) + 16))
+        step(i, r, c, dd)
+        ms, cn = (C.c_double * 5)(), (C.c_int64 * 5)()
+        _lib.check(lib.vaenmf_profile_read(r.eng._plan, ms, cn))
+        _lib.check(lib.vaenmf_profile_enable(r.eng._plan, 0))
+        return list(ms), list(cn)
+
+    def chain_roofline(ms, cn, F_, fpu, counts_list, niter, r, trans=True):
+        """roofline of the MH-chain kernel from a profiled step: algorithmic decoder flops per launch / HIP-event time"""
+        _, flop_row = algorithmic(F_, niter, r.nsE, r.nsW)
+        chain_ms = ms[0] / max(cn[0], 1)
+        rows = []
+        for counts in counts_list:
+            rows += [len(counts) * fpu * (r.nsE + r.biE)] * niter + [len(counts) * fpu * (r.nsW + r.biW)]
+        rows_avg = float(np.mean(rows))
+        achieved = flop_row * rows_avg / (chain_ms * 1e-3) / 1e12 if chain_ms > 0 else 0.0
+        trans_per_row = 2 * 256 + 2 * F_
+        t_trans = trans_per_row * rows_avg / 64.0 * TRANS_CYCLES / (1024 * 2.4e9)      # 1024 SIMDs at the 2.4 GHz peak clock
+        return {"bound": "mfma", "kernel": "wchain_kernel (MH chain)", "achieved": achieved, "peak": PEAK_BF16_DENSE / 1e12,
+                "unit": "TFLOP/s", "frac": achieved * 1e12 / PEAK_BF16_DENSE, "avg_launch_ms": chain_ms, "flop_per_row": flop_row,
+                "rows_per_launch": rows_avg,
+                "valu_issue": {"transcendentals_per_row": trans_per_row, "cycles_per_wave_instruction": TRANS_CYCLES,
+                               "floor_ms": t_trans * 1e3, "frac": t_trans * 1e3 / chain_ms if chain_ms > 0 else None}}
+
+    def committed_traffic(tag):
+        """HBM bytes per launch per kernel from the committed rocprofv3 PMC passes of this command (profiles/, newest round
+        first; FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as is).  Returns (kernels, source, error)."""
+        for rnd in ("round3", "round2", "round1"):
+            fn = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (rnd, tag))
+            if os.path.exists(fn):
+                tj = json.load(open(fn))
+                if "kernels" not in tj:
+                    return None, fn, "profiles/%s has no 'kernels' key" % os.path.basename(fn)
+                return tj["kernels"], "profiles/" + os.path.basename(fn), None
+        return None, None, "no profiles/round*_%s_traffic.json committed" % tag
+
+    def traffic_of(kern, sub, src):
+        hit = [v["hbm_bytes_per_launch"] for k, v in kern.items() if sub in k]
+        if not hit:
+            raise KeyError("%s: no kernel matching '%s' (a renamed kernel? re-run tools/profile.sh and commit the summary)" % (src, sub))
+        return hit[0]
+
+    ms, cn = profiled_step(rec, clf, data, args.warmup + args.steps, args.niter)
+
+    # ---- the other BASELINE configs (rank 0 of a 1-GPU run), one 64-utterance batch each: two untimed calls (the eager
+    # one and the graph capture), then the median of three timed, synchronised calls on the REPLAYED graph; then a
+    # profiled call for the kernel breakdown and the chain's roofline
     configs = []
     par = None
+    cfg1_gpu = None
     if world == 1 and not strong and rank == 0:
         del rec
         torch.cuda.empty_cache()
@@ -337,49 +428,80 @@ def main():
                      ("reference scripts' STFT: 1024-pt (F=513), rank 10", "M1", 1024, 10, args.precision, None),
                      ("config 5 shape (stress): 1024-pt STFT, rank 32 (100 of its 500 iterations)", "M1", 1024, 32, args.precision, None)]
         for name, model, nf, K, prec, st_ in todo:
-            note("one step of: " + name)
+            note("config: " + name)
             r2, c2 = make_rec(model, nf, K, prec, st_)
-            step(0, r2, c2, b64)
+            for w in range(2):
+                step(w, r2, c2, b64)
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            _, cst = step(1, r2, c2, b64)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter() - t1
-            e = {"name": name, "dtype": prec, "frames_per_s": BATCH * r2.frame_counts[0] / t2, "ms_per_step": t2 * 1e3,
+            ts = []
+            for k in range(3):
+                t1 = time.perf_counter()
+                _, cst = step(2 + k, r2, c2, b64)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+            t2 = sorted(ts)[1]
+            gflag = graph_flag(r2)
+            F2, fpu = nf // 2 + 1, r2.frame_counts[0]
+            ms2, cn2 = profiled_step(r2, c2, b64, 9, args.niter)
+            bpf2, _ = algorithmic(F2, args.niter, r2.nsE, r2.nsW)
+            fps = BATCH * fpu / t2
+            e = {"name": name, "dtype": prec, "frames_per_s": fps, "ms_per_step": t2 * 1e3, "ms_per_step_all": [round(t * 1e3, 3) for t in ts],
+                 "timing": "median of 3 synchronised calls after 2 untimed ones", "em_graph_replayed": gflag,
                  "final_cost_mean": float(cst[:, -1].mean().item()),
-                 "m_step_path": {1: "stored", 2: "decode"}.get(_lib.lib().vaenmf_plan_query(r2.eng._plan, _lib.Q_MSTEP_PATH), "?")}
+                 "m_step_path": {1: "stored", 2: "decode"}.get(lib.vaenmf_plan_query(r2.eng._plan, _lib.Q_MSTEP_PATH), "?"),
+                 "kernels": {k: {"ms_total": round(ms2[i], 3), "launches": int(cn2[i])} for i, k in enumerate(KNAMES)},
+                 "roofline": chain_roofline(ms2, cn2, F2, fpu, [b64[0][4]], args.niter, r2),
+                 "hbm_equiv": {"algorithmic_bytes_per_frame": bpf2, "frac_of_8TBps": fps * bpf2 / PEAK_HBM}}
             if name.startswith("parity-grade"):
-                par = {"dtype": "bf16x3", "value": e["frames_per_s"], "unit": "frames/s", "ms_per_step": e["ms_per_step"], "m_step_path": e["m_step_path"]}
+                par = dict(e, value=fps, unit="frames/s")
             else:
                 configs.append(e)
             del r2
             torch.cuda.empty_cache()
+
+        # ---- BASELINE config 1 on the GPU: ONE 4 s utterance through the drop-in class (the reference's call pattern,
+        # scripts/evaluate_M1.py:111-166: init_parameters + run per utterance on one object), device generator, same
+        # workload as cpu_baseline; the engine is built by the first call and reused by the others
+        if not args.no_configs and args.model == "M1":
+            import vaenmf
+            from vaenmf import stft as vstft
+            note("config 1 on the GPU: one utterance through MCEM_M1.init_parameters / run")
+            vae = vaenmf.VariationalAutoencoder([F, 32, [128, 128]])
+            vae.load_state_dict({k: torch.tensor(v) for k, v in xavier_normal_params([F, 32, [128, 128]], seed=0).items()})
+            x1 = base[0][2]
+            X1 = vstft.stft(x1, fs=fs, wlen_sec=nfft / fs, hop_percent=0.25).T
+            m1 = vaenmf.MCEM_M1(niter=args.niter, rng="device", precision=args.precision)
+            ts, allocs = [], []
+            for k in range(4):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                m1.init_parameters(X=X1, vae=vae, nmf_rank=args.rank_k, eps=1e-8, device=str(dev))
+                c1 = m1.run()
+                ts.append(time.perf_counter() - t1)
+                allocs.append(int(lib.vaenmf_plan_query(m1._eng._plan, _lib.Q_DEV_ALLOCS)))
+            t1u = sorted(ts[1:])[1]
+            cfg1_gpu = {"workload": "BASELINE config 1: one 4 s utterance (%d frames, F=%d, K=%d), %d EM iterations + Wiener chain through "
+                                    "MCEM_M1.init_parameters + run (rng='device', %s, batch of one: the decoding M-step)" % (X1.shape[0], F, args.rank_k, args.niter, args.precision),
+                        "value": X1.shape[0] / t1u, "unit": "frames/s", "seconds_per_utterance": t1u,
+                        "seconds_all_calls": [round(t, 4) for t in ts], "timing": "median of calls 2-4 (call 1 builds the engine)",
+                        "device_allocations_after_each_call": allocs, "final_cost": float(c1[-1])}
+            del m1
 
     if rank == 0:
         n_total = int(nutt.item())
         frames = n_total * frames_per_utt * args.steps
         value = frames / dt
         bpf, flop_row = algorithmic(F, args.niter, nsE, nsW)
-        chain_ms = ms[0] / max(cn[0], 1)
-        rows_per_launch = []
-        for (_, _, _, _, counts) in data:
-            rows_per_launch += [len(counts) * frames_per_utt * (nsE + biE)] * args.niter + [len(counts) * frames_per_utt * (nsW + biW)]
-        rows_avg = float(np.mean(rows_per_launch))
-        achieved = flop_row * rows_avg / (chain_ms * 1e-3) / 1e12 if chain_ms > 0 else 0.0
-        # transcendental-issue roofline of the chain: per decoder row 256 tanh (exp + rcp) and F bins (exp, 1/2 log, 1/2 rcp)
-        trans_per_row = 2 * 256 + 2 * F
-        t_trans = trans_per_row * rows_avg / 64.0 * TRANS_CYCLES / (1024 * 2.4e9)      # 1024 SIMDs at the 2.4 GHz peak clock
-        traffic, traffic_src = None, None
-        for cand in ("round2_%s_traffic.json" % args.precision, "round1_%s_traffic.json" % args.precision):
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
-                traffic = [v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items() if "chain_kernel" in k][0]
-                traffic_src = "profiles/" + cand
-                break
-            except Exception:
-                pass
-        kernels = {k: {"ms_total": round(ms[i], 3), "launches": int(cn[i])}
-                   for i, k in enumerate(["mh_chain", "m_wstats", "w_update", "m_hg", "wiener"])}
+        rl = chain_roofline(ms, cn, F, frames_per_utt, [d_[4] for d_ in data], args.niter,
+                            type("R", (), {"nsE": nsE, "biE": biE, "nsW": nsW, "biW": biW}))
+        tag = args.precision if args.model == "M1" and nfft == 512 and args.rank_k == 8 else "%s_%s_f%d_k%d" % (args.precision, args.model, F, args.rank_k)
+        kern, traffic_src, terr = committed_traffic(tag)
+        rl["traffic"] = traffic_of(kern, "chain_kernel", traffic_src) if kern else None
+        rl["traffic_source"] = ("%s (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this command; not measured in this run)" % traffic_src) if kern else terr
+        rl["note"] = ("algorithmic decoder flops (1 proposal decode per MH step, %d flop/row) / HIP-event launch time of a profiled step "
+                      "outside the timed region; the bf16x3 mode issues 3 MFMAs per algorithmic product; valu_issue = the bound of the "
+                      "kernel's own instruction stream (v_exp/v_log/v_rcp_f32: 8.2 cycles per wave-instruction per SIMD, 1024 SIMDs, 2.4 GHz)" % flop_row)
+        kernels = {k: {"ms_total": round(ms[i], 3), "launches": int(cn[i])} for i, k in enumerate(KNAMES)}
         iter_ms = sum(ms[i] / max(cn[i], 1) for i in range(4))
         workload = (("fixed %d-utterance set sharded over %d GPU(s) in batches of <= %d" % (n_total, world, BATCH)) if strong
                     else ("%d-utterance batch per GPU" % args.utts))
@@ -393,55 +515,53 @@ def main():
                                    % (workload, args.model, nfft, F, frames_per_utt, args.rank_k, args.niter, nsE + biE, nsE, nsW + biW, nsW),
                        "utterances_total": n_total, "utterances_rank0": len(ids), "batches_rank0": [len(b) for b in batches],
                        "parallelism": "utterance-shard x%d (np.array_split, no collective in the loop)" % world},
-            "roofline": {"bound": "mfma", "kernel": "wchain_kernel (MH chain)", "achieved": achieved, "peak": PEAK_BF16_DENSE / 1e12,
-                         "unit": "TFLOP/s", "frac": achieved * 1e12 / PEAK_BF16_DENSE, "traffic": traffic,
-                         "traffic_source": ("%s (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of this command; not measured in this run)" % traffic_src) if traffic_src else None,
-                         "avg_launch_ms": chain_ms,
-                         "note": "algorithmic decoder flops (1 proposal decode per MH step, %d flop/row) / HIP-event launch time of a "
-                                 "profiled step outside the timed region; the bf16x3 mode issues 3 MFMAs per algorithmic product" % flop_row,
-                         "valu_issue": {"transcendentals_per_row": trans_per_row, "cycles_per_wave_instruction": TRANS_CYCLES,
-                                        "floor_ms": t_trans * 1e3, "frac": t_trans * 1e3 / chain_ms if chain_ms > 0 else None,
-                                        "note": "the kernel's real bound: v_exp/v_log/v_rcp_f32 issue (8.2 cycles per wave-instruction "
-                                                "per SIMD, no overlap between resident waves; 1024 SIMDs, 2.4 GHz)"}},
+            "collective_backend": backend,
+            "em_graph_replayed": main_graph,
+            "roofline": rl,
             "hbm_equiv": {"algorithmic_bytes_per_frame": bpf, "achieved_GBps": value * bpf / 1e9, "frac_of_8TBps": value * bpf / PEAK_HBM,
                           "note": "SURVEY 8(d) B_utt CREDIT (fp32 sample variances written once, read by W-, H-, g-update and cost per "
-                                  "iteration); the build moves fewer real bytes -- see measured_hbm"},
+                                  "iteration): a credit, not a bandwidth -- the build moves fewer real bytes, see measured_hbm"},
             "m_step_path": m_step_path,
             "kernels": kernels,
+            "kernels_note": "HIP events of rank 0's profiled step" + (" (the other ranks run the same kernels on their shards)" if world > 1 else ""),
             "si_sdr_mean_db": float(st[0, 0, 1] / max(st[0, 0, 0], 1)),
             "final_cost_mean": float(cost[:, -1].mean().item()),
         }
-        try:        # real HBM bytes per EM iteration from the committed PMC passes, against the measured iteration time
-            tj = json.load(open(os.path.join(ROOT, "profiles", traffic_src.split("/", 1)[1])))
-            per_iter = sum(v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()
-                           if any(s in k for s in ("chain_kernel", "wstats_stream", "wstats_rot", "hg_stream", "w_partial", "w_update")))
+        if kern:        # real HBM bytes per EM iteration from the committed PMC passes, against this run's kernel time per iteration
+            subs = [("chain_kernel",), ("wstats_stream", "wstats_rot", "wstats_fused"), ("hg_stream",), ("w_partial",), ("w_update", "w_final")]
+            per_iter, missing = 0.0, []
+            for alt in subs:
+                hit = [v["hbm_bytes_per_launch"] for k, v in kern.items() if any(a_ in k for a_ in alt)]
+                if hit:
+                    per_iter += hit[0]
+                elif alt[0] not in ("w_partial",):        # (fused into the W-statistics kernel in later builds)
+                    missing.append("/".join(alt))
             out["measured_hbm"] = {"bytes_per_em_iteration": per_iter, "GBps": per_iter / (iter_ms * 1e-3) / 1e9,
-                                   "frac_of_8TBps": per_iter / (iter_ms * 1e-3) / PEAK_HBM,
-                                   "note": "rocprofv3 PMC bytes (committed profile, not this run) / this run's kernel time per EM iteration"}
-        except Exception:
-            pass
-        try:        # what this GPU gives a plain streaming read (outside the timed region): the practical ceiling of the M-step kernels
-            probe = torch.empty(130 * 1024 * 1024, dtype=torch.float32, device=dev).fill_(1.0)      # 520 MB, the size of the sample store
-            probe.sum(); torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                probe.sum()
-            e1.record(); torch.cuda.synchronize()
-            out["stream_read_probe"] = {"GBps": probe.numel() * 4 / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9, "bytes": probe.numel() * 4,
-                                        "note": "torch.sum over a 520 MB float buffer, 10 repetitions: the read bandwidth a plain streaming kernel gets on this "
-                                                "GPU (the W-statistics kernel's rows + operands stream at about this rate); not part of the timed region"}
-            del probe
-        except Exception:
-            pass
+                                   "frac_of_8TBps": per_iter / (iter_ms * 1e-3) / PEAK_HBM, "kernels_missing_from_profile": missing,
+                                   "note": "rocprofv3 PMC bytes (%s, not this run) / this run's kernel time per EM iteration" % traffic_src}
+        else:
+            out["measured_hbm"] = {"error": terr}
+        # what this GPU delivers to a hand-written streaming read of the sample store's size (vaenmf_hbm_read_probe: 16 B per
+        # lane, 8 wavefronts per SIMD, grid = resident set), outside the timed region
+        pbuf = torch.empty(130 * 1024 * 1024, dtype=torch.float32, device=dev).normal_()
+        sink = torch.zeros(4, dtype=torch.int32, device=dev)
+        gb = C.c_double()
+        _lib.check(lib.vaenmf_hbm_read_probe(C.c_void_p(pbuf.data_ptr()), pbuf.numel() * 4, 10, C.c_void_p(sink.data_ptr()), C.byref(gb),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        out["hbm_read_probe"] = {"GBps": gb.value, "bytes": pbuf.numel() * 4, "frac_of_8TBps": gb.value * 1e9 / PEAK_HBM,
+                                 "note": "hand-written HIP read kernel (aux.hip: 16 B per lane, 8 wavefronts per SIMD, 4 loads in flight per lane, grid = "
+                                         "resident set) over a 520 MB buffer, 10 sweeps: a measured rate of one kernel on this GPU, not a bound"}
+        del pbuf
         if configs:
             out["configs"] = configs
         if par is not None:
             out["parity_mode"] = par
+        if cfg1_gpu is not None:
+            out["config_1_gpu"] = cfg1_gpu
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(F, args.rank_k, args.niter)
+            out["cpu_baseline"] = cpu_baseline(F, args.rank_k, args.niter, args.cpu_slice_utts)
         print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

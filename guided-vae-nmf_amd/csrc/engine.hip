@@ -1385,6 +1385,7 @@ int check_bound(const vaenmf_plan* p) {
 
 }  // namespace
 
+extern long long g_vn_dev_allocs;      // plan.hip
 // chain.hip
 bool vn_wchain_supported(const vaenmf_plan* p);
 bool vn_wchain_fits(const vaenmf_plan* p, const VnChainCall& cc);
@@ -1466,12 +1467,14 @@ extern "C" int vaenmf_sample_store(vaenmf_plan* p, int32_t max_samples) {
     if (p->VsS) VN_CHECK_HIP(hipFree(p->VsS));
     p->VsS = nullptr; p->VsS_cap = 0;
     VN_CHECK_HIP(hipMalloc(&p->VsS, need_v));
+    ++g_vn_dev_allocs;
     p->VsS_cap = need_v;
   }
   if (need_s > p->src_cap) {
     if (p->src) VN_CHECK_HIP(hipFree(p->src));
     p->src = nullptr; p->src_cap = 0;
     VN_CHECK_HIP(hipMalloc(&p->src, need_s * sizeof(int32_t)));
+    ++g_vn_dev_allocs;
     p->src_cap = need_s;
   }
   p->Rcap_store = max_samples;

@@ -34,6 +34,8 @@ void vaenmf_set_error(const char* fmt, ...) {
 }
 extern "C" const char* vaenmf_last_error(void) { return g_err; }
 
+long long g_vn_dev_allocs = 0;      // device allocations made by the library in this process (VAENMF_Q_DEV_ALLOCS)
+
 namespace {
 
 uint16_t bf16_rne(float v) {                 // round-to-nearest-even, NaN kept quiet
@@ -74,6 +76,7 @@ std::vector<uint16_t> pack_weights(const float* W, int out, int in, int ldw, int
 template <typename T>
 int dev_alloc(T** p, size_t n) {
   VN_CHECK_HIP(hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));
+  ++g_vn_dev_allocs;
   return 0;
 }
 template <typename T>
@@ -184,6 +187,7 @@ extern "C" int vaenmf_plan_query(const vaenmf_plan* p, int32_t what) {
     case VAENMF_Q_MSTEP_PATH: return p->last_m_step_path;
     case VAENMF_Q_WTILES: return p->n_wtiles;
     case VAENMF_Q_EM_GRAPH: return p->last_em_graph;
+    case VAENMF_Q_DEV_ALLOCS: return (int)g_vn_dev_allocs;
     default: return -1;
   }
 }

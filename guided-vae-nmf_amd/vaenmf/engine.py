@@ -156,7 +156,10 @@ class BatchEngine:
 
     def _dev(self, a):
         """Device copy of a host weight array, uploaded once per array object (an upload from pageable memory per call
-        makes the host wait for the GPU)."""
+        makes the host wait for the GPU).  CONTRACT: weight arrays handed to encode() / classify() are immutable -- the
+        copy is keyed by the array object, so an array modified in place would keep its stale device copy; pass a new
+        array (or call invalidate_weight_caches()) to change weights.  The drop-in classes (vaenmf.mcem) rebuild their
+        engine when a model tensor's in-place version counter moves."""
         cache = self.__dict__.setdefault("_w_cache", {})
         ent = cache.get(id(a))
         if ent is None or ent[0] is not a:
@@ -164,6 +167,11 @@ class BatchEngine:
                 cache.clear()
             ent = cache[id(a)] = (a, torch.from_numpy(_np32(a)).to(self.device))
         return ent[1]
+
+    def invalidate_weight_caches(self):
+        """Forget the device copies of encoder / classifier weights (after modifying weight arrays in place)."""
+        self.__dict__.pop("_w_cache", None)
+        self.__dict__.pop("_clf_cache", None)
 
     def encode(self, enc, y=None):
         """Z = posterior mean of encoder(|X|^2 [cat y]) (mcem.py:367-368 / :214-215).

@@ -24,6 +24,16 @@ def _state(vae):
     return {k: v.detach().cpu() for k, v in vae.state_dict().items()}
 
 
+def _weights_key(vae):
+    """Identity of a model's weights: storage address, in-place version counter (load_state_dict, an optimiser step or
+    any other in-place write bumps it) and shape of every state_dict entry."""
+    try:
+        sd = vae.state_dict(keep_vars=True)
+    except TypeError:
+        sd = vae.state_dict()
+    return (id(vae),) + tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in sd.items())
+
+
 def _encoder_params(sd):
     enc, i = [], 0
     while "encoder.hidden.%d.weight" % i in sd:
@@ -44,13 +54,13 @@ class _MCEM:
         self.var_RW = var_RW
         self.rng, self.precision, self.reference_compat = rng, precision, reference_compat
         self.Vs = self.Vs_scaled = self.Vx = None
-        self._eng = None
+        self._eng = self._eng_key = self._enc = None
         self._call = 0
 
     # picklable like the reference object (sent through a spawn Pool, evaluate_M1.py:206-216)
     def __getstate__(self):
         d = dict(self.__dict__)
-        for k in ("_eng", "vae"):
+        for k in ("_eng", "vae", "_eng_key", "_enc"):
             d[k] = None
         return {k: v for k, v in d.items() if not isinstance(v, torch.Tensor) or not v.is_cuda}
 
@@ -69,15 +79,25 @@ class _MCEM:
             raise NameError("MCEM algorithm only valid for FFNN VAE")         # mcem.py:362-363
         dev = torch.device(device if device not in (None, "cpu") else "cuda:0")
         N, F = X.shape
-        sd = _state(vae)
-        dec = decoder_params_from_state(sd)
         L = getattr(vae, "latent_dim", None) or getattr(vae, "z_dim")
         if L != LAT:
             raise NotImplementedError("latent dim %d: this build supports %d" % (L, LAT))
         ns_e, _ = self.e_step_counts()
         ns_w, _ = self.wf_counts()
         self.device, self.vae = dev, vae
-        eng = BatchEngine(F, nmf_rank, dec, precision=self.precision, device=dev, max_frames=N, max_utts=1)
+        # The reference calls init_parameters once per utterance on ONE object (scripts/evaluate_M1.py:111-166): the engine
+        # (plan, packed decoder weights, device buffers, encoder weights on the device) is kept across calls while the model,
+        # its weights (identity and in-place version of every tensor), F, K, precision and device stay the same, and grows
+        # when an utterance has more frames than any before it.
+        key = (F, int(nmf_rank), self.precision, str(dev), max(ns_e, ns_w), _weights_key(vae))
+        eng = self._eng
+        if eng is None or self._eng_key != key or N > eng._max_frames:
+            sd = _state(vae)
+            cap = N if (eng is None or self._eng_key != key) else max(N, 2 * eng._max_frames)
+            if eng is not None:
+                eng.close()
+            eng = BatchEngine(F, nmf_rank, decoder_params_from_state(sd), precision=self.precision, device=dev, max_frames=cap, max_utts=1)
+            self._enc, self._eng_key = _encoder_params(sd), key
         eng.bind([N], Rcap=max(ns_e, ns_w))
         self._eng, self._N, self._F, self._K = eng, N, F, nmf_rank
         # draw order of the reference: rand(F,K), rand(K,N) (mcem.py:42-43)
@@ -92,7 +112,7 @@ class _MCEM:
             eng.set_labels(yy)
             self.y = torch.t(yy)                                               # mcem.py:213
         torch.randn(N, L)                      # the encoder's reparametrisation draw (models.py:10), unused
-        eng.encode(_encoder_params(sd), yy)
+        eng.encode(self._enc, yy)
         self._call = 0
         self.Vs = self.Vs_scaled = self.Vx = None
 

@@ -54,7 +54,9 @@ enum { VAENMF_RNG_REPLAY = 0,    /* caller supplies the normal / uniform draws (
 enum { VAENMF_Q_FS = 0, VAENMF_Q_KP = 1, VAENMF_Q_TILES = 2, VAENMF_Q_NT = 3, VAENMF_Q_NUTT = 4,
        VAENMF_Q_MSTEP_PATH = 5,  /* M-step path of the last vaenmf_em_run: 1 = streaming the sample store, 2 = decoding */
        VAENMF_Q_WTILES = 6,      /* 16-frame wave tiles of the bound batch */
-       VAENMF_Q_EM_GRAPH = 7 };  /* 1 when the last vaenmf_em_run was launched as a captured HIP graph, 0 when launch by launch */
+       VAENMF_Q_EM_GRAPH = 7,    /* 1 when the last vaenmf_em_run was launched as a captured HIP graph, 0 when launch by launch */
+       VAENMF_Q_DEV_ALLOCS = 8 };/* device allocations the library has made in this process so far (any plan): a caller that
+                                    reuses a plan can check that a call allocated nothing */
 
 enum { VAENMF_ACT_NONE = 0, VAENMF_ACT_TANH = 1, VAENMF_ACT_RELU = 2, VAENMF_ACT_SIGMOID = 3,
        VAENMF_ACT_STEP = 4 };   /* 1 if x > 0 else 0: sigmoid(x) > 0.5, scripts/evaluate_M2_vad.py:131 */
@@ -99,7 +101,9 @@ int vaenmf_bind_batch(vaenmf_plan* p, int32_t n_utt, const int32_t* frame_offset
 /* The same without waiting for the GPU when the batch's frame structure repeats the bound one:
  * the frame tables stay, the seeds go up stream-ordered from pinned memory.  A caller that never
  * synchronises (results collected later) can prepare batch k+1 while batch k runs.  A batch with
- * another frame structure synchronises `stream` and uploads the tables as vaenmf_bind_batch does. */
+ * another frame structure synchronises `stream` and uploads the tables as vaenmf_bind_batch does.
+ * STREAM CONTRACT: the seed upload is ordered on `stream` only -- the calls that consume the batch (vaenmf_mh_chain,
+ * vaenmf_em_run, ...) must be enqueued on the same stream, or after an event / synchronisation that orders them behind it. */
 int vaenmf_bind_batch_async(vaenmf_plan* p, int32_t n_utt, const int32_t* frame_offsets,
                             const uint64_t* utt_seeds, void* stream);
 

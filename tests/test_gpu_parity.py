@@ -1054,3 +1054,57 @@ def test_fused_run_with_the_sample_store():
     cb, Sb, Nb = run(True, 4)
     assert np.max(np.abs(ca.cpu().numpy() - cb.cpu().numpy()) / np.abs(ca.cpu().numpy())) < 5e-3
     assert np.all(np.isfinite(Sb.cpu().numpy())) and np.all(np.isfinite(cb.cpu().numpy()))
+
+
+def test_drop_in_object_reuses_its_engine_across_utterances():
+    """scripts/evaluate_M1.py:111-166 calls init_parameters once per utterance on ONE MCEM object.  The second call with
+    the same model reuses the plan, the packed weights and every device buffer (no device allocation by the library, none
+    by torch's allocator), gives the results a fresh object gives, and a model whose weights were written in place gets a
+    new engine."""
+    need_gpu()
+    import vaenmf
+    from vaenmf import _lib
+    z, params, draws, meta = load_case("m1_f65")
+    nsE, biE, nsW, biW = meta["counts"]
+    vae = vaenmf.VariationalAutoencoder([meta["F"], meta["L"], [128, 128]])
+    vae.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+    mk = lambda: vaenmf.MCEM_M1(niter=meta["niter"], nsamples_E_step=nsE, burnin_E_step=biE, nsamples_WF=nsW, burnin_WF=biW, var_RW=0.01)
+    m = mk()
+    runs = []
+    for rep in range(3):
+        torch.manual_seed(int(z["seed"]))
+        if rep:
+            torch.cuda.synchronize()
+            a0 = _lib.lib().vaenmf_plan_query(m._eng._plan, _lib.Q_DEV_ALLOCS)
+            r0, eng0, plan0 = torch.cuda.memory_reserved(), m._eng, m._eng._plan.value
+        m.init_parameters(X=z["X"], vae=vae, nmf_rank=meta["K"], eps=1e-8, device="cuda:0")
+        if rep:
+            assert m._eng is eng0 and m._eng._plan.value == plan0
+            assert _lib.lib().vaenmf_plan_query(m._eng._plan, _lib.Q_DEV_ALLOCS) == a0        # the library allocated nothing
+            assert torch.cuda.memory_reserved() == r0                                         # nor did torch's allocator
+        c = m.run()
+        runs.append((c.copy(), m.S_hat.copy()))
+    assert np.max(np.abs(runs[0][0] - z["cost"]) / np.abs(z["cost"])) < 2e-4
+    for c, s in runs[1:]:                                   # the reused engine gives the first run's result bit for bit
+        assert np.array_equal(c, runs[0][0]) and np.array_equal(s, runs[0][1])
+    # a shorter utterance on the same object: still the same engine; a longer one grows it
+    eng0 = m._eng
+    torch.manual_seed(1)
+    m.init_parameters(X=z["X"][:10], vae=vae, nmf_rank=meta["K"], eps=1e-8, device="cuda:0")
+    assert m._eng is eng0 and m.run().shape == (meta["niter"],) and m.S_hat.shape == (meta["F"], 10)
+    Xl = np.concatenate([z["X"], z["X"]], 0)
+    m.init_parameters(X=Xl, vae=vae, nmf_rank=meta["K"], eps=1e-8, device="cuda:0")
+    assert m._eng is not eng0 and m._eng._max_frames >= Xl.shape[0]
+    assert np.all(np.isfinite(m.run())) and m.S_hat.shape == (meta["F"], Xl.shape[0])
+    # weights written in place (load_state_dict copies in place): the engine is rebuilt with the new weights
+    eng1 = m._eng
+    with torch.no_grad():
+        vae.decoder.reconstruction.bias.add_(0.25)
+    torch.manual_seed(int(z["seed"]))
+    m.init_parameters(X=z["X"], vae=vae, nmf_rank=meta["K"], eps=1e-8, device="cuda:0")
+    assert m._eng is not eng1
+    c2 = m.run()
+    assert np.max(np.abs(c2 - runs[0][0])) > 1e-3          # other weights, other costs
+    import pickle
+    m2 = pickle.loads(pickle.dumps(m))                     # still picklable (spawn Pool, evaluate_M1.py:206-216)
+    assert m2._eng is None and m2.niter == m.niter
