@@ -97,6 +97,55 @@ __global__ __launch_bounds__(640) void w_update_kernel(const float* __restrict__
   }
 }
 
+// The same update from the per-tile partial sums of wstats_fused_kernel (stream.hip): part [tile][2 KP][Fs], the tiles of
+// utterance u are tile_first[u] .. tile_first[u+1]-1, added in that order; a tile's block is slot-major: [2 k + stat][Fs].
+template <int KP>
+__global__ __launch_bounds__(640) void w_update_tiles_kernel(const float* __restrict__ part, const int32_t* __restrict__ tile_first,
+                                                             float* __restrict__ W, float* __restrict__ normW, int F, int Fs, int K) {
+  __shared__ float colred[10][KP];
+  const int u = blockIdx.x, f = threadIdx.x;
+  float wn[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) wn[k] = 0.f;
+  if (f < F) {
+    float num[KP], den[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) num[k] = den[k] = 0.f;
+    const int t0 = tile_first[u], t1 = tile_first[u + 1];
+    for (int t = t0; t < t1; ++t) {                       // fixed order: deterministic
+      const float* src = part + (size_t)t * 2 * KP * Fs + f;        // [slot = 2 k + stat][Fs]: coalesced over the bins
+#pragma unroll
+      for (int k = 0; k < KP; ++k) { num[k] += src[(size_t)(2 * k) * Fs]; den[k] += src[(size_t)(2 * k + 1) * Fs]; }
+    }
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+      if (k < K) wn[k] = W[((size_t)u * Fs + f) * KP + k] * sqrtf(num[k] / den[k]);          // mcem.py:110
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    const float v = sum_rows4(sum_row16(fabsf(wn[k])));
+    if (lane == 0) colred[wv][k] = v;
+  }
+  __syncthreads();
+  float nrm[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    float s = 0.f;
+    for (int ww = 0; ww < nwv; ++ww) s += colred[ww][k];
+    nrm[k] = s;
+  }
+  if (f < Fs) {
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+      W[((size_t)u * Fs + f) * KP + k] = (k < K && f < F) ? wn[k] / nrm[k] : 0.f;              // mcem.py:131
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < KP; ++k) normW[(size_t)u * KP + k] = (k < K) ? nrm[k] : 0.f;         // applied to H (mcem.py:133)
+  }
+}
+
 // cost[u][it] = mean_{r,f,n}(log Vx + X2/Vx)  (mcem.py:70) from per-frame sums
 __global__ void cost_reduce_kernel(const double* __restrict__ cost_frames, const int32_t* __restrict__ frame_off,
                                    int R, int F, double* __restrict__ cost, int niter, int it) {
@@ -342,6 +391,17 @@ int vn_launch_w_update(const vaenmf_plan* p, float* W, const float* Ht, hipStrea
   } while (0)
   switch (p->Kp) { case 8: VN_WU(8); break; case 16: VN_WU(16); break; default: VN_WU(32); break; }
 #undef VN_WU
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int vn_launch_w_update_tiles(const vaenmf_plan* p, float* W, hipStream_t st) {
+  const int threads = ((p->Fs + 63) / 64) * 64;
+  switch (p->Kp) {
+    case 8: hipLaunchKernelGGL((w_update_tiles_kernel<8>), dim3(p->n_utt), dim3(threads), 0, st, p->wpart64, p->d_t64_first, W, p->normW, p->cfg.F, p->Fs, p->cfg.K); break;
+    case 16: hipLaunchKernelGGL((w_update_tiles_kernel<16>), dim3(p->n_utt), dim3(threads), 0, st, p->wpart64, p->d_t64_first, W, p->normW, p->cfg.F, p->Fs, p->cfg.K); break;
+    default: hipLaunchKernelGGL((w_update_tiles_kernel<32>), dim3(p->n_utt), dim3(threads), 0, st, p->wpart64, p->d_t64_first, W, p->normW, p->cfg.F, p->Fs, p->cfg.K); break;
+  }
   VN_CHECK_HIP(hipGetLastError());
   return 0;
 }

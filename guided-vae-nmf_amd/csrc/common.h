@@ -60,6 +60,12 @@ struct vaenmf_plan {
   int NT3c;                  // ceil(F / 16)
   int32_t *d_wt_utt, *d_wt_n0, *d_wt_cnt;         // wave tiles (<= 16 frames of one utterance each)
   int n_wtiles;
+  // tiles of <= 64 consecutive frames of one utterance (wstats_fused_kernel: one workgroup per tile) and the partial sums of
+  // the W update, one [Fs][2 Kp] block per tile
+  int32_t *d_t64_n0 = nullptr, *d_t64_cnt = nullptr, *d_t64_first = nullptr;      // [n_t64], [n_t64], [n_utt+1]
+  int n_t64 = 0;
+  float* wpart64 = nullptr;
+  int last_w_fused = 0;      // VAENMF_Q_W_FUSED: 1 when the last stored M-step ran the fused W-statistics kernel
   int Rcap_store;            // samples per frame the store was sized for at vaenmf_bind_batch / vaenmf_sample_store
   int last_m_step_path;      // VAENMF_Q_MSTEP_PATH: 0 none yet, 1 stored (streaming), 2 decoding
   uint64_t* d_utt_seed;      // [n_utt]

@@ -156,6 +156,11 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   e |= dev_alloc(&p->normW, Uc * p->Kp);
   e |= dev_alloc(&p->wpart, Uc * 8 * p->Fs * 2 * p->Kp);
   e |= dev_alloc(&p->cost_frames, NTc);
+  const size_t max_t64 = NTc / 64 + Uc + 1;
+  e |= dev_alloc(&p->d_t64_n0, max_t64);
+  e |= dev_alloc(&p->d_t64_cnt, max_t64);
+  e |= dev_alloc(&p->d_t64_first, Uc + 1);
+  e |= dev_alloc(&p->wpart64, max_t64 * p->Fs * 2 * p->Kp);
   if (e) { vaenmf_plan_destroy(p); return -2; }
   *out = p;
   return 0;
@@ -165,7 +170,8 @@ extern "C" void vaenmf_plan_destroy(vaenmf_plan* p) {
   if (!p) return;
   void* ptrs[] = {p->w1f, p->w2f, p->w3f, p->b1, p->b2, p->b3, p->w3n, p->w1y, p->d_frame_off, p->d_tile_utt, p->d_tile_n0,
                   p->d_tile_cnt, p->d_frame_utt, p->d_frame_loc, p->d_utt_seed, p->A1, p->P, p->normW, p->wpart, p->cost_frames,
-                  p->VsS, p->src, p->w3c, p->b3c, p->d_wt_utt, p->d_wt_n0, p->d_wt_cnt};
+                  p->VsS, p->src, p->w3c, p->b3c, p->d_wt_utt, p->d_wt_n0, p->d_wt_cnt, p->d_t64_n0, p->d_t64_cnt, p->d_t64_first,
+                  p->wpart64};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
@@ -188,6 +194,7 @@ extern "C" int vaenmf_plan_query(const vaenmf_plan* p, int32_t what) {
     case VAENMF_Q_WTILES: return p->n_wtiles;
     case VAENMF_Q_EM_GRAPH: return p->last_em_graph;
     case VAENMF_Q_DEV_ALLOCS: return (int)g_vn_dev_allocs;
+    case VAENMF_Q_W_FUSED: return p->last_w_fused;
     default: return -1;
   }
 }
@@ -283,6 +290,15 @@ extern "C" int vaenmf_bind_batch_async(vaenmf_plan* p, int32_t n_utt, const int3
         w_n0.push_back(n);
         w_cnt.push_back(frame_offsets[u + 1] - n < 16 ? frame_offsets[u + 1] - n : 16);
       }
+    std::vector<int32_t> t64_n0, t64_cnt, t64_first(n_utt + 1);   // <= 64-frame tiles of the fused W-statistics kernel
+    for (int u = 0; u < n_utt; ++u) {
+      t64_first[u] = (int32_t)t64_n0.size();
+      for (int n = frame_offsets[u]; n < frame_offsets[u + 1]; n += 64) {
+        t64_n0.push_back(n);
+        t64_cnt.push_back(frame_offsets[u + 1] - n < 64 ? frame_offsets[u + 1] - n : 64);
+      }
+    }
+    t64_first[n_utt] = (int32_t)t64_n0.size();
     VN_CHECK_HIP(hipStreamSynchronize(st));               // kernels of the previous batch may still read the tables
     int e = 0;
     e |= upload(p->d_frame_off, frame_offsets, (size_t)n_utt + 1);
@@ -294,6 +310,10 @@ extern "C" int vaenmf_bind_batch_async(vaenmf_plan* p, int32_t n_utt, const int3
     e |= upload(p->d_wt_utt, w_utt.data(), w_utt.size());
     e |= upload(p->d_wt_n0, w_n0.data(), w_n0.size());
     e |= upload(p->d_wt_cnt, w_cnt.data(), w_cnt.size());
+    e |= upload(p->d_t64_n0, t64_n0.data(), t64_n0.size());
+    e |= upload(p->d_t64_cnt, t64_cnt.data(), t64_cnt.size());
+    e |= upload(p->d_t64_first, t64_first.data(), t64_first.size());
+    p->n_t64 = (int)t64_n0.size();
     if (e) return -2;
     p->n_wtiles = (int)w_utt.size();
     p->n_tiles = (int)t_utt.size();

@@ -78,6 +78,10 @@ struct StreamArgs {
   int store_f32;               // rows are float (bf16x3 mode) rather than bf16
   int w_blk_lds;               // rank > 8: W of the workgroup's first utterance is staged in LDS
   int n_sms;
+  // W statistics fused with the W update's sums (wstats_fused_kernel): tiles of <= 64 frames of one utterance
+  const int32_t *t64_n0, *t64_cnt;
+  int n_t64;
+  float* wpart64;              // [n_t64][2 KP slots: 2 k + stat][Fs]
 };
 
 __device__ __forceinline__ float wave_sum(float v) { return sum_rows4(sum_row16(v)); }
@@ -1081,6 +1085,145 @@ __global__ __launch_bounds__(256, 2) void wstats_rot_kernel(const StreamArgs a) 
 }
 
 
+// ----------------------------------------------------------------------------
+// W statistics AND the W update's sums over frames in one pass (mcem.py:107-110): wstats_rot's frame loop, but the
+// frame's A1 = sum_r 1/Vx and P = X2 sum_r 1/Vx^2 never leave the registers -- each wavefront adds P[f] H[k, n] and
+// A1[f] H[k, n] of its frames to 2 x 4 bins x KP accumulators per lane (the extra bin F-1: lane k keeps rank k), the four
+// wavefronts of a workgroup (one tile of <= 64 consecutive frames of ONE utterance, 16 per wavefront) add theirs up
+// through LDS in fixed order, and the workgroup writes one partial sum [Fs][2 KP] per tile.  w_update_tiles_kernel
+// (aux.hip) adds an utterance's tiles in fixed order.  Against wstats_rot + w_partial: no A1 / P round trip through
+// HBM (2 x NT x Fs floats written and read back) and one launch less per EM iteration; sums in a fixed order, so
+// results are reproducible run to run.
+// ----------------------------------------------------------------------------
+constexpr int WF_TILE = 64, WF_WFR = 16;            // frames per workgroup tile / per wavefront
+// LDS of a workgroup: W of the tile's utterance, rank-major [KP][Fs] (shared by the four wavefronts: they are in one
+// utterance by construction), then per wavefront 2 KP accumulator rows [slot = 2 k + stat][lane][4 bins] (a lane reads and
+// writes its 16 bytes of a slot: conflict-free ds_read/write_b128) and 2 x 64 floats for the extra bin.  The accumulators
+// live in LDS, not in registers: wstats_rot's two register sets of rows leave no room for 64 more (it spilled 175).
+template <int KP>
+__host__ __device__ constexpr int wf_acc_floats() { return 2 * KP * 256 + 128; }
+template <int KP, int RT>
+__global__ __launch_bounds__(256, 2) void wstats_fused_kernel(const StreamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  FrameCtx<1, KP, __bf16> fc(a, wlds);
+  float* acc_all = wlds + (size_t)a.Fs * KP;
+  float* acc = acc_all + (size_t)wave * wf_acc_floats<KP>();
+  RotCtx<KP, RT> rc(a, fc);
+  const unsigned l4 = (unsigned)fc.lane * 4u;
+  for (int tile = blockIdx.x; tile < a.n_t64; tile += gridDim.x) {
+    const int t_n0 = a.t64_n0[tile], t_cnt = a.t64_cnt[tile];
+    const int utt = a.frame_utt[t_n0];
+    // ---- W of the utterance into LDS (all four wavefronts), this wavefront's accumulators to zero
+    __syncthreads();                                    // the previous tile's readers are done
+    if (utt != fc.wutt) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(a.W + (size_t)utt * a.Fs * KP);
+      for (int e = threadIdx.x; e < a.Fs * KP / 4; e += 256) fc.put_t(e, src[e]);
+      fc.wutt = utt;                                    // (set_utt below then only refreshes the extra bin's column)
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < 2 * KP; ++sidx) *reinterpret_cast<f32x4*>(acc + sidx * 256 + l4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    float numx = 0.f, denx = 0.f;
+    __syncthreads();
+    const int n_beg = t_n0 + wave * WF_WFR;
+    const int n_end = n_beg + WF_WFR < t_n0 + t_cnt ? n_beg + WF_WFR : t_n0 + t_cnt;
+    if (n_beg < n_end) {
+      RotSmall<KP> cur, nx1, nx2;
+      int sl[2];
+      const int n_last = n_end - 1;
+      auto clampf = [&](int n) { return n < n_last ? n : n_last; };
+      {
+        sl[0] = rc.slots(n_beg);
+        rc.req_small(n_beg, cur);
+        rc.req_small(clampf(n_beg + 1), nx1);
+        sl[1] = rc.slots(clampf(n_beg + 1));
+#pragma unroll
+        for (int r = 0; r < RT; ++r) rc.template req_row<0>(n_beg, sl[0], r, 0.f, rc.voff);
+        rc.template req_x<0>(n_beg, sl[0], true);
+      }
+      auto step = [&](int n, auto set_c) {
+        constexpr int S = decltype(set_c)::value, T = 1 - S;
+        const bool more = n < n_last;
+        const int nn = clampf(n + 1);
+        rc.req_small(clampf(n + 2), nx2);
+        sl[S] = rc.slots(clampf(n + 2));
+        const float gn = cur.g();
+        fc.set_utt(utt);
+        float h[KP];
+        rot_h<KP>(cur.pk, h);
+        f32x4 vb[1], a1, a2;
+        float vbx;
+        fc.noise_var(utt, h, vb, vbx);
+        a1 = a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x2 g2 = {gn, gn};
+        const unsigned vnext = more ? rc.voff : 0xF0000000u;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          const f32x4 v = rc.template row<S>(r);
+          const f32x2 q0 = rcp2(g2 * v.lo + vb[0].lo), q1 = rcp2(g2 * v.hi + vb[0].hi);
+          a1.lo += q0; a1.hi += q1;
+          a2.lo = q0 * q0 + a2.lo; a2.hi = q1 * q1 + a2.hi;
+          rc.template req_row<T>(nn, sl[T], r, a2[3], vnext);
+          __builtin_amdgcn_sched_barrier(0);             // one row per region
+        }
+        const float q = fast_rcp(gn * rc.template x<S>() + vbx) * rc.xmask();
+        rc.template req_x<T>(nn, sl[T], more);
+        const float a1x = wave_sum(q), a2x = wave_sum(q * q);
+        a2 *= cur.x2;                                                     // P = X2 sum_r 1/Vx^2   (mcem.py:107)
+        // sums over frames of P H^T and A1 H^T (mcem.py:108-109), this wavefront's share, four ranks per round trip to LDS
+#pragma unroll
+        for (int k0 = 0; k0 < KP; k0 += 4) {
+          f32x4 nv[4], dv[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            nv[t] = *reinterpret_cast<const f32x4*>(acc + (2 * (k0 + t)) * 256 + l4);
+            dv[t] = *reinterpret_cast<const f32x4*>(acc + (2 * (k0 + t) + 1) * 256 + l4);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            *reinterpret_cast<f32x4*>(acc + (2 * (k0 + t)) * 256 + l4) = a2 * h[k0 + t] + nv[t];
+            *reinterpret_cast<f32x4*>(acc + (2 * (k0 + t) + 1) * 256 + l4) = a1 * h[k0 + t] + dv[t];
+          }
+        }
+        const float hl = fc.lane < KP ? cur.pk : 0.f;                      // lane k: H[k, n]
+        numx = (a2x * cur.x2x()) * hl + numx;
+        denx = a1x * hl + denx;
+        cur = nx1;
+        nx1 = nx2;
+      };
+      int n = n_beg;
+      for (; n < n_last; n += 2) {
+        step(n, std::integral_constant<int, 0>{});
+        step(n + 1, std::integral_constant<int, 1>{});
+      }
+      if (n == n_last) step(n, std::integral_constant<int, 0>{});
+    }
+    acc[2 * KP * 256 + fc.lane] = numx;
+    acc[2 * KP * 256 + 64 + fc.lane] = denx;
+    __syncthreads();
+    // ---- the four wavefronts' sums added in the fixed order 0, 1, 2, 3; the tile's partial [slot = 2 k + stat][Fs]
+    // (a wavefront writes whole 1 KB pieces: this lane's four bins of a slot are 16 contiguous bytes)
+    float* dst = a.wpart64 + (size_t)tile * 2 * KP * a.Fs;
+    for (int sidx = wave; sidx < 2 * KP; sidx += 4) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(acc_all + sidx * 256 + l4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(acc_all + (size_t)w * wf_acc_floats<KP>() + sidx * 256 + l4);
+      if (fc.cv[0]) *reinterpret_cast<f32x4*>(dst + (size_t)sidx * a.Fs + fc.f0[0]) = v;
+    }
+    if (wave == 0 && fc.has_x && fc.lane < KP) {          // the extra bin F-1: lane k holds rank k
+      float vn = 0.f, vd = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        vn += acc_all[(size_t)w * wf_acc_floats<KP>() + 2 * KP * 256 + fc.lane];
+        vd += acc_all[(size_t)w * wf_acc_floats<KP>() + 2 * KP * 256 + 64 + fc.lane];
+      }
+      dst[(size_t)(2 * fc.lane) * a.Fs + a.F - 1] = vn;
+      dst[(size_t)(2 * fc.lane + 1) * a.Fs + a.F - 1] = vd;
+    }
+  }
+}
+
+
 StreamArgs base_args(const vaenmf_plan* p) {
   StreamArgs a = {};
   a.VsS = p->VsS; a.src = p->src; a.frame_utt = p->d_frame_utt; a.Vb = p->Vb_ext;
@@ -1191,6 +1334,32 @@ int check_store(const vaenmf_plan* p) {
 
 // aux.hip
 int vn_launch_w_update(const vaenmf_plan* p, float* W, const float* Ht, hipStream_t st);
+int vn_launch_w_update_tiles(const vaenmf_plan* p, float* W, hipStream_t st);
+
+namespace {
+// W statistics + the W update's sums in one kernel: the bench shapes of wstats_rot (bf16 rows, one 256-bin chunk, rank <= 8,
+// 30 or 10 samples per frame, NMF noise model).  VAENMF_WFUSED=0 keeps the two-kernel path (A/B runs, tests).
+bool w_fused_ok(const vaenmf_plan* p, const StreamArgs& a) {
+  if (!(VN_ROT && !a.store_f32 && p->Kp == 8 && (p->Fm + 255) / 256 == 1 && (a.R == 30 || a.R == 10) && !a.gains_only)) return false;
+  const char* e = getenv("VAENMF_WFUSED");              // (read per call: tests switch it inside one process)
+  return !(e && e[0] == '0');
+}
+int launch_w_fused(const vaenmf_plan* p, StreamArgs a, hipStream_t st) {
+  a.t64_n0 = p->d_t64_n0; a.t64_cnt = p->d_t64_cnt; a.n_t64 = p->n_t64; a.wpart64 = p->wpart64;
+  const size_t lds = ((size_t)a.Fs * 8 + (size_t)4 * wf_acc_floats<8>()) * sizeof(float);
+  int grid = a.n_sms * 2;                               // one resident set: 2 workgroups of 4 wavefronts per CU
+  if (grid > p->n_t64) grid = p->n_t64;
+  if (a.R == 30) {
+    if (int e = vn_ensure_dyn_lds((const void*)wstats_fused_kernel<8, 30>, 80 * 1024)) return e;
+    hipLaunchKernelGGL((wstats_fused_kernel<8, 30>), dim3(grid), dim3(256), lds, st, a);
+  } else {
+    if (int e = vn_ensure_dyn_lds((const void*)wstats_fused_kernel<8, 10>, 80 * 1024)) return e;
+    hipLaunchKernelGGL((wstats_fused_kernel<8, 10>), dim3(grid), dim3(256), lds, st, a);
+  }
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
 
 extern "C" int vaenmf_m_step_stored(vaenmf_plan* p, const float* X2, float* W, float* Ht, float* g, double* cost_frames,
                                     void* stream) {
@@ -1204,8 +1373,14 @@ extern "C" int vaenmf_m_step_stored(vaenmf_plan* p, const float* X2, float* W, f
     ProfScope ps(p, VN_K_HG, st);
     return launch_stream<SK_HG>(p, a, st);
   }
-  { ProfScope ps(p, VN_K_WSTATS, st); if (int e = launch_stream<SK_WSTATS>(p, a, st)) return e; }
-  { ProfScope ps(p, VN_K_WUPDATE, st); if (int e = vn_launch_w_update(p, W, Ht, st)) return e; }
+  p->last_w_fused = w_fused_ok(p, a) ? 1 : 0;
+  if (p->last_w_fused) {
+    { ProfScope ps(p, VN_K_WSTATS, st); if (int e = launch_w_fused(p, a, st)) return e; }
+    { ProfScope ps(p, VN_K_WUPDATE, st); if (int e = vn_launch_w_update_tiles(p, W, st)) return e; }
+  } else {
+    { ProfScope ps(p, VN_K_WSTATS, st); if (int e = launch_stream<SK_WSTATS>(p, a, st)) return e; }
+    { ProfScope ps(p, VN_K_WUPDATE, st); if (int e = vn_launch_w_update(p, W, Ht, st)) return e; }
+  }
   { ProfScope ps(p, VN_K_HG, st); if (int e = launch_stream<SK_HG>(p, a, st)) return e; }
   return 0;
 }

@@ -1108,3 +1108,42 @@ def test_drop_in_object_reuses_its_engine_across_utterances():
     import pickle
     m2 = pickle.loads(pickle.dumps(m))                     # still picklable (spawn Pool, evaluate_M1.py:206-216)
     assert m2._eng is None and m2.niter == m.niter
+
+
+@pytest.mark.parametrize("R,counts", [(30, [21, 64, 130, 9, 65]), (10, [70, 5, 64])])
+def test_fused_w_statistics_equal_the_two_kernel_path(R, counts):
+    """wstats_fused_kernel (W statistics and the W update's sums over frames in one pass, one partial per <= 64-frame tile,
+    mcem.py:107-110) against wstats_rot + w_partial + w_update from the same store: the same W, normalisation and --
+    through the H/g kernel that follows -- H, g, cost, up to the order of the float sums over frames (2e-5); ragged
+    utterances: tiles of 64, 2, 1 frames, wavefronts without frames.  The fused path is reproducible bit for bit."""
+    need_gpu()
+    from vaenmf import _lib
+    F, K = 257, 8
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=5, bias_std=0.05)
+    g = np.random.default_rng(R + len(counts))
+    Xs = [((g.standard_normal((n, F)) + 1j * g.standard_normal((n, F))) * (0.5 + 3 * np.exp(-np.arange(F) / 60.0))).astype(np.complex64) for n in counts]
+    W0 = [np.maximum(g.random((F, K)), 1e-8).astype(np.float32) for _ in counts]
+    H0 = [np.maximum(g.random((K, n)), 1e-8).astype(np.float32) for n in counts]
+    gains = (0.5 + g.random(sum(counts))).astype(np.float32)
+
+    def run(fused):
+        os.environ["VAENMF_WFUSED"] = "1" if fused else "0"
+        try:
+            eng = make_engine(params, F, K, counts, Rcap=R, precision="bf16", seeds=list(range(len(counts))))
+            eng.set_spectrogram(Xs)
+            eng.init_nmf(W0, H0)
+            eng.g.copy_(torch.from_numpy(gains))
+            eng.sample_store(True)
+            eng.mh_chain(R, 3, 0.01, call=0)
+            c = eng.m_step_stored().clone()
+            assert _lib.lib().vaenmf_plan_query(eng._plan, _lib.Q_W_FUSED) == (1 if fused else 0)
+            return [t.cpu().numpy().copy() for t in (eng.W, eng.Ht, eng.g, c)]
+        finally:
+            os.environ.pop("VAENMF_WFUSED", None)
+
+    a, b, a2 = run(True), run(False), run(True)
+    for x, y, name in zip(a, b, ("W", "Ht", "g", "cost")):
+        assert np.max(np.abs(x - y) / (np.abs(y) + 1e-20)) < 2e-5, name
+    for x, y in zip(a, a2):
+        assert np.array_equal(x, y)
+    assert float(np.abs(a[0][:, F:]).max()) == 0.0 and float(np.abs(a[0][:, :, K:]).max()) == 0.0 if a[0].shape[2] > K else True
