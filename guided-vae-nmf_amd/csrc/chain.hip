@@ -82,6 +82,8 @@ struct WcArgs {
   int b1_lds;                      // M2 at 8 wavefronts: byte offset of the per-wave stash of the layer-1 bias rows
   uint32_t call;
   float sd;
+  float sd_hi;                     // step of latents 16..31 (0: they are padding of a 16-dimensional latent space)
+  int one_hidden;                  // decoder with one hidden layer: layer 2 is skipped
 };
 
 template <bool SPLIT>
@@ -410,7 +412,11 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
                   [&](int t, const f32x4 acc) { put(ch, cl, t, tanh4(acc)); });
       }
       WC_STAMP(1);
-      // ---- layer 2
+      // ---- layer 2 (a decoder with ONE hidden layer, models.py:107-121 with h_dim = [128], hands layer 1's output on)
+      if (a.one_hidden) {
+#pragma unroll
+        for (int s = 0; s < NK; ++s) { bh[s] = ch[s]; if (SPLIT) bl[s] = cl[s]; }
+      } else
       run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, NTH>{},
                 [&](int t, int s, bf16x8& hi, bf16x8& lo) {
                   const char* p = smem + L::W2 + (t * NK + s) * PARTS * 1024 + l16;
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
           const float uu = q == 0 ? uniform01(st0) : 0.5f;
           const f32x4 e1 = normal4(st1);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) { zp[t] = z[t] + a.sd * e0[t]; zp[4 + t] = z[4 + t] + a.sd * e1[t]; }
+          for (int t = 0; t < 4; ++t) { zp[t] = z[t] + a.sd * e0[t]; zp[4 + t] = z[4 + t] + a.sd_hi * e1[t]; }
           lu = q == 0 ? fast_log(uu) : 0.f;
         } else {
           const unsigned so = (unsigned)m * (unsigned)a.NT;      // step offset in rows
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
           const f32x4 e1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(eps_rs, rp_off + so * (LAT * 4u) + 64u, 0, 0));
           const float uu = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(u_rs, (unsigned)nrow * 4u + so * 4u, 0, 0));
 #pragma unroll
-          for (int t = 0; t < 4; ++t) { zp[t] = z[t] + a.sd * e0[t]; zp[4 + t] = z[4 + t] + a.sd * e1[t]; }
+          for (int t = 0; t < 4; ++t) { zp[t] = z[t] + a.sd * e0[t]; zp[4 + t] = z[4 + t] + a.sd_hi * e1[t]; }
           lu = q == 0 ? fast_log(uu) : 0.f;
 #pragma unroll
           for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(zp[t]));
@@ -669,7 +675,7 @@ int vn_launch_wchain(vaenmf_plan* p, const VnChainCall& cc, hipStream_t st) {
   a.wt_utt = p->d_wt_utt; a.wt_n0 = p->d_wt_n0; a.wt_cnt = p->d_wt_cnt; a.n_wtiles = p->n_wtiles;
   a.frame_off = p->d_frame_off; a.utt_seed = p->d_utt_seed; a.eps = cc.eps; a.u = cc.u;
   a.Kp = p->Kp; a.NT = p->NT; a.n_utts = p->n_utt; a.Rcap = cc.Rcap; a.nsamples = cc.nsamples; a.burnin = cc.burnin;
-  a.rng_mode = cc.rng_mode; a.update_Z = cc.update_Z; a.call = cc.call; a.sd = cc.sd;
+  a.rng_mode = cc.rng_mode; a.update_Z = cc.update_Z; a.call = cc.call; a.sd = cc.sd; a.sd_hi = cc.sd_hi; a.one_hidden = cc.one_hidden;
   a.n_hi_lds = p->NT3c;
   const size_t fixed = split ? WcLds<true>::fixed_bytes : WcLds<false>::fixed_bytes;
   constexpr int GT33 = 4;                                // F = 513: bin tiles whose fragments stay in global memory

@@ -46,6 +46,8 @@ struct vaenmf_plan {
   float *b1, *b2, *b3;       // biases (b3 padded to 16*NT3)
   float* w1y;                // [H1][Dy] label columns of W1 (M2)
   int Dy;
+  int Lz;                    // latent dimension of the model (16 or 32): latents Lz..31 of the MFMA path are zero padding
+  bool one_hidden;           // decoder with ONE hidden layer (h_dim = [128]): layer 2 is skipped
   bool have_weights;
   const float* Vb_ext;       // caller-owned noise variance [NT][Fs] (noNMF variants) or null
   // bound batch
@@ -114,6 +116,8 @@ struct VnChainCall {
   int Rcap, nsamples, burnin, rng_mode, update_Z;
   uint32_t call;
   float sd;
+  float sd_hi;               // random-walk step of latents 16..31: sd, or 0 when they are padding (latent dimension 16)
+  int one_hidden;
 };
 
 enum { VN_K_CHAIN = 0, VN_K_WSTATS = 1, VN_K_WUPDATE = 2, VN_K_HG = 3, VN_K_WF = 4, VN_K_NKINDS = 5 };
@@ -236,14 +240,27 @@ __device__ __forceinline__ Xs128 xs_seed(uint64_t utt_seed, uint32_t frame, uint
   if ((s.s0 | s.s1 | s.s2 | s.s3) == 0) s.s0 = 1;
   return s;
 }
-// 4 standard normals from 4 random words (two Box-Muller pairs); v_sin/v_cos take revolutions.
+// 4 standard normals (two Box-Muller pairs); v_sin/v_cos take revolutions.
+// VN_RNG16 = 1: ONE random word per pair -- radius from its high 16 bits, angle from its low 16 bits -- instead of two
+// words at 24 bits each: half the generator steps (the proposals are N(0, var_RW) steps of a random walk: a radius on a
+// 2^-16 grid, |eps| <= 4.71 sigma, changes nothing the sampler's distribution can show; any symmetric proposal leaves
+// the Metropolis-Hastings target unchanged).
+#ifndef VN_RNG16
+#define VN_RNG16 0
+#endif
 __device__ __forceinline__ f32x4 normal4(Xs128& st) {
   f32x4 o;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
+#if VN_RNG16
+    const uint32_t a = st.next();
+    const float u1 = ((float)(a >> 16) + 1.0f) * 1.52587890625e-5f;  // (0,1], 2^-16 grid
+    const float u2 = (float)(a & 0xFFFFu) * 1.52587890625e-5f;       // [0,1)
+#else
     uint32_t a = st.next(), b = st.next();
     float u1 = ((float)(a >> 8) + 1.0f) * 5.9604644775390625e-8f;   // (0,1]
     float u2 = (float)(b >> 8) * 5.9604644775390625e-8f;            // [0,1)
+#endif
     float r = __builtin_amdgcn_sqrtf(-2.0f * fast_log(u1));
     o[2 * p] = r * __builtin_amdgcn_cosf(u2);
     o[2 * p + 1] = r * __builtin_amdgcn_sinf(u2);

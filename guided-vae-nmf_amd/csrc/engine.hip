@@ -32,6 +32,8 @@ struct DecW {                      // decoder weights (device), fragment order [
   int F;                           // bins
   int Fm;                          // bins on the MFMA path: F-1 when F = 16k+1 (n_fft/2+1: the Nyquist bin would
                                    // cost a whole 16-row tile, a fifth of one wave's work), else F
+  int Lz;                          // latent dimension of the model (latents Lz..31 are zero padding: no random-walk noise)
+  int one_hidden;                  // decoder with one hidden layer: the output layer reads layer 1's image
 };
 
 // A workgroup = NTEAM teams x NW waves.  The NW waves of a team split the output features of
@@ -114,6 +116,7 @@ struct Dec {
   const char* w3g;      // global W3 fragments of this wave's first tile (uniform pointer)   [!W3LDS]
   const char* w3l;      // LDS W3 fragments                                                  [W3LDS]
   int w, team, NT3;
+  int one_hidden;       // decoder with ONE hidden layer (models.py:107-121, h_dim = [128]): act2 == act1, layer 2 skipped
   unsigned lane16;
   bool nyq;             // the odd last bin is computed beside the tiles
   f32x4 wn[NT_H / NW];  // its weights for this lane's hidden features (rows 4q+t of this wave's layer-2 tiles)
@@ -183,6 +186,31 @@ struct Dec {
   // `between` runs after the first barrier (all waves have consumed the previous step's noise).
   template <typename F>
   __device__ __forceinline__ void hidden(const bf16x8 (&zhi)[2], const bf16x8 (&zlo)[2], const f32x4 (&bias1)[TPW][2], F between) const {
+    if (one_hidden) {       // (wave-uniform) layer 1 is the last hidden layer: its image is the output layer's input
+      float pn[2] = {0.f, 0.f};
+#pragma unroll
+      for (int ti = 0; ti < TPW; ++ti) {
+        const int tile = w + NW * ti;
+        bf16x8 whi, wlo;
+        lds_w(M::w1, tile, 1, 0, whi, wlo);
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+          const f32x4 h = tanh4(mma3<SPLIT>(whi, wlo, zhi[cg], zlo[cg], bias1[ti][cg]));
+          store_h(act1, cg, tile, h);
+          pn[cg] += h[0] * wn[ti][0] + h[1] * wn[ti][1] + h[2] * wn[ti][2] + h[3] * wn[ti][3];
+        }
+      }
+      if (nyq) {
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+          const float v = sum_rows4(pn[cg]);
+          if ((lane16 >> 8) == 0) nyqbuf[(w * 2 + cg) * 16 + ((lane16 >> 4) & 15)] = v;
+        }
+      }
+      team_sync();
+      between();
+      return;
+    }
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
       const int tile = w + NW * ti;
@@ -302,7 +330,8 @@ __device__ __forceinline__ Dec<NW, NTEAM, MT, SPLIT, W3LDS> dec_setup(char* smem
   d.lane16 = (threadIdx.x & 63) * 16;
   d.NT3 = dw.NT3;
   d.act1 = smem + M::act + d.team * M::ACT_TEAM;
-  d.act2 = M::ALIAS ? d.act1 : d.act1 + M::ACT;
+  d.one_hidden = dw.one_hidden;
+  d.act2 = (M::ALIAS || dw.one_hidden) ? d.act1 : d.act1 + M::ACT;
   d.w3g = reinterpret_cast<const char*>(dw.w3f) + (size_t)d.w * NK_H * 2 * 1024;
   d.w3l = smem + (W3LDS ? w3_lds_off : 0);
   d.nyq = dw.Fm != dw.F;
@@ -498,6 +527,7 @@ __global__ __launch_bounds__(NW * NTEAM * 64) void mh_chain_kernel(const ChainAr
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), gfx9 encoding
       }
     }
+    if (4 * squad >= a.dw.Lz) e = f32x4{0, 0, 0, 0};      // padding of a 16-dimensional latent space: no random walk
     *reinterpret_cast<f32x4*>(&L.eps[sfr][4 * squad]) = e;
     if (squad == 0) L.u[sfr] = uu;
   };
@@ -1291,6 +1321,7 @@ DecW make_decw(const vaenmf_plan* p) {
   d.w1f = p->w1f; d.w2f = p->w2f; d.w3f = p->w3f;
   d.b1 = p->b1; d.b2 = p->b2; d.b3 = p->b3;
   d.NT3 = p->NT3; d.F = p->cfg.F; d.Fm = p->Fm; d.w3n = p->w3n;
+  d.Lz = p->Lz; d.one_hidden = p->one_hidden ? 1 : 0;
   return d;
 }
 
@@ -1427,7 +1458,7 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
   cc.X2 = X2; cc.W = W; cc.Ht = Ht; cc.g = g; cc.B1 = B1; cc.Z = Z; cc.Zs = Zs; cc.acc_out = acc_out;
   cc.eps = rng->eps; cc.u = rng->u; cc.VsS = a.VsS; cc.VsS_bytes = vss_bytes; cc.src = a.src; cc.Rs = a.Rs;
   cc.Rcap = Rcap; cc.nsamples = nsamples; cc.burnin = burnin; cc.rng_mode = rng->mode; cc.update_Z = update_Z;
-  cc.call = rng->call; cc.sd = a.sd;
+  cc.call = rng->call; cc.sd = a.sd; cc.sd_hi = p->Lz > 16 ? a.sd : 0.f; cc.one_hidden = p->one_hidden ? 1 : 0;
   // wave-private chains (chain.hip) while every buffer of the batch is within their 32-bit byte offsets; a larger batch
   // (about 300 k frames at 105 samples) runs the team kernel below, which addresses with 64 bits
   if (vn_wchain_supported(p) && vn_wchain_fits(p, cc)) {

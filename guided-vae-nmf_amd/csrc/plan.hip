@@ -89,8 +89,10 @@ int upload(T* dst, const T* src, size_t n) {
 
 extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   VN_REQUIRE(cfg && out, "null argument");
-  VN_REQUIRE(cfg->L == LAT, "this build supports latent dim %d (got %d)", LAT, cfg->L);
-  VN_REQUIRE(cfg->H1 == HID && cfg->H2 == HID, "this build supports hidden sizes %d,%d (got %d,%d)", HID, HID, cfg->H1, cfg->H2);
+  // decoder shapes: z(32 or 16) -> 128 [-> 128] -> F.  Latent dimension 16 runs the 32-wide first layer with zero padding
+  // (no random-walk noise on the padding); H2 = 0 is a decoder with ONE hidden layer (the reference's h_dim = [128]).
+  VN_REQUIRE(cfg->L == LAT || cfg->L == 16, "this build supports latent dims %d and 16 (got %d)", LAT, cfg->L);
+  VN_REQUIRE(cfg->H1 == HID && (cfg->H2 == HID || cfg->H2 == 0), "this build supports hidden sizes %d[,%d] (got %d,%d)", HID, HID, cfg->H1, cfg->H2);
   VN_REQUIRE(cfg->F >= 1 && cfg->F <= 640, "F=%d out of range (1..640)", cfg->F);
   VN_REQUIRE(cfg->K >= 1 && cfg->K <= 32, "NMF rank K=%d out of range (1..32)", cfg->K);
   VN_REQUIRE(cfg->max_frames >= 1 && cfg->max_utts >= 1, "bad capacities");
@@ -117,6 +119,8 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   p->d_wt_utt = p->d_wt_n0 = p->d_wt_cnt = nullptr;
   p->n_wtiles = 0; p->Rcap_store = 0; p->last_m_step_path = 0;
   p->Dy = 0;
+  p->Lz = cfg->L;
+  p->one_hidden = cfg->H2 == 0;
   p->have_weights = false;
   p->Vb_ext = nullptr;
   p->store_on = false; p->VsS = nullptr; p->src = nullptr; p->VsS_cap = p->src_cap = 0; p->store_R = p->store_Rs = 0;
@@ -201,9 +205,25 @@ extern "C" int vaenmf_plan_query(const vaenmf_plan* p, int32_t what) {
 
 extern "C" int vaenmf_set_decoder_weights(vaenmf_plan* p, const float* W1, int32_t in1, const float* b1, const float* W2,
                                           const float* b2, const float* W3, const float* b3) {
-  VN_REQUIRE(p && W1 && b1 && W2 && b2 && W3 && b3, "null argument");
-  VN_REQUIRE(in1 >= LAT, "decoder input width %d < latent dim %d", in1, LAT);
+  VN_REQUIRE(p && W1 && b1 && W3 && b3, "null argument");
+  VN_REQUIRE(p->one_hidden || (W2 && b2), "null second-layer weights (plan with H2 = %d)", p->cfg.H2);
+  const int Lz = p->Lz;
+  VN_REQUIRE(in1 >= Lz, "decoder input width %d < latent dim %d", in1, Lz);
   const int F = p->cfg.F;
+  // first layer on the 32-wide MFMA k-step: [H][32 latent columns (zero beyond Lz) | Dy label columns]
+  std::vector<float> W1pad;
+  const int in1m = in1 - Lz + LAT;
+  if (Lz != LAT) {
+    W1pad.assign((size_t)HID * in1m, 0.f);
+    for (int h = 0; h < HID; ++h) {
+      memcpy(&W1pad[(size_t)h * in1m], W1 + (size_t)h * in1, sizeof(float) * Lz);
+      memcpy(&W1pad[(size_t)h * in1m + LAT], W1 + (size_t)h * in1 + Lz, sizeof(float) * (in1 - Lz));
+    }
+    W1 = W1pad.data();
+    in1 = in1m;
+  }
+  const std::vector<float> W2zero(p->one_hidden ? (size_t)HID * HID : 0, 0.f), b2zero(p->one_hidden ? HID : 0, 0.f);
+  if (p->one_hidden) { W2 = W2zero.data(); b2 = b2zero.data(); }   // (never read by the kernels: layer 2 is skipped)
   // pre-scale so that the accumulators are v_exp_f32 arguments (common.h: fast_tanh / fast_exp)
   const double C2 = 2.0 * 1.4426950408889634, C1 = 1.4426950408889634;
   auto scaled = [](const float* src, size_t n, double c) {

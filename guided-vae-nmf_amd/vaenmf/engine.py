@@ -31,34 +31,51 @@ def decoder_params_from_state(sd, prefix="decoder."):
     n = 0
     while (prefix + "hidden.%d.weight" % n) in sd:
         n += 1
+    if n == 1:            # h_dim = [128] (scripts/evaluate_M1.py:44-85 lists such checkpoints): [W1, b1, W3, b3]
+        return [get("hidden.0.weight"), get("hidden.0.bias"), get("reconstruction.weight"), get("reconstruction.bias")]
     if n != 2:
-        raise NotImplementedError("this build runs decoders with 2 hidden layers (got %d)" % n)
+        raise NotImplementedError("this build runs decoders with 1 or 2 hidden layers of 128 units (got %d layers)" % n)
     return [get("hidden.0.weight"), get("hidden.0.bias"), get("hidden.1.weight"), get("hidden.1.bias"),
             get("reconstruction.weight"), get("reconstruction.bias")]
 
 
+def latent_dim_from_state(sd):
+    """z_dim of a model from its state_dict (encoder.sample.mu.weight is (z_dim, h))."""
+    return int(sd["encoder.sample.mu.weight"].shape[0])
+
+
 class BatchEngine:
-    def __init__(self, F, K, decoder, precision="bf16x3", device="cuda:0", max_frames=1 << 16, max_utts=256):
-        """decoder = [W1 (H,L+Dy), b1, W2 (H,H), b2, W3 (F,H), b3] float32 numpy (nn.Linear layout)."""
+    def __init__(self, F, K, decoder, precision="bf16x3", device="cuda:0", max_frames=1 << 16, max_utts=256, z_dim=LAT):
+        """decoder = [W1 (H,L+Dy), b1, W2 (H,H), b2, W3 (F,H), b3] float32 numpy (nn.Linear layout), or [W1, b1, W3, b3]
+        for a decoder with one hidden layer (h_dim = [128]).  z_dim = L: 32 or 16 (16 runs on the 32-wide first layer with
+        zero padding: Z / Zs keep 32 columns, the last 16 stay zero)."""
         if not torch.cuda.is_available():
             raise RuntimeError("vaenmf needs a ROCm GPU (MI355X); there is no CPU path")
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
-        W1, b1, W2, b2, W3, b3 = [_np32(a) for a in decoder]
-        if W1.shape[0] != HID or W2.shape != (HID, HID) or W3.shape != (F, HID):
-            raise NotImplementedError("this build runs decoders z(%d)+y -> %d -> %d -> F; got %s %s %s"
-                                      % (LAT, HID, HID, W1.shape, W2.shape, W3.shape))
-        self.F, self.K, self.L = int(F), int(K), LAT
-        self.Dy = W1.shape[1] - LAT
+        dec = [_np32(a) for a in decoder]
+        if len(dec) == 4:
+            W1, b1, W3, b3 = dec
+            W2 = b2 = None
+        else:
+            W1, b1, W2, b2, W3, b3 = dec
+        if W1.shape[0] != HID or (W2 is not None and W2.shape != (HID, HID)) or W3.shape != (F, HID):
+            raise NotImplementedError("this build runs decoders z(32|16)+y -> %d [-> %d] -> F; got %s %s %s"
+                                      % (HID, HID, W1.shape, None if W2 is None else W2.shape, W3.shape))
+        if int(z_dim) not in (16, LAT):
+            raise NotImplementedError("latent dim %d: this build supports 16 and %d (z_dim 128 would need 4 k-steps in the "
+                                      "first layer and 128 latents per frame in registers)" % (z_dim, LAT))
+        self.F, self.K, self.L = int(F), int(K), int(z_dim)
+        self.Dy = W1.shape[1] - self.L
         if self.Dy < 0:
-            raise NotImplementedError("latent dim must be %d" % LAT)
+            raise NotImplementedError("first decoder layer has %d inputs, fewer than the latent dim %d" % (W1.shape[1], self.L))
         self.precision = {"bf16x3": _lib.PREC_BF16X3, "bf16": _lib.PREC_BF16}[precision]
         self._max_frames, self._max_utts = int(max_frames), int(max_utts)
-        cfg = _lib.Config(self.F, self.K, LAT, HID, HID, int(max_frames), int(max_utts), self.precision)
+        cfg = _lib.Config(self.F, self.K, self.L, HID, HID if W2 is not None else 0, int(max_frames), int(max_utts), self.precision)
         self._plan = C.c_void_p()
         check(lib().vaenmf_plan_create(C.byref(cfg), C.byref(self._plan)))
-        check(lib().vaenmf_set_decoder_weights(self._plan, W1.ctypes.data, W1.shape[1], b1.ctypes.data, W2.ctypes.data,
-                                               b2.ctypes.data, W3.ctypes.data, b3.ctypes.data))
+        check(lib().vaenmf_set_decoder_weights(self._plan, W1.ctypes.data, W1.shape[1], b1.ctypes.data, None if W2 is None else W2.ctypes.data,
+                                               None if b2 is None else b2.ctypes.data, W3.ctypes.data, b3.ctypes.data))
         self.Fs = lib().vaenmf_plan_query(self._plan, _lib.Q_FS)
         self.Kp = lib().vaenmf_plan_query(self._plan, _lib.Q_KP)
         self.NT = 0
@@ -184,7 +201,12 @@ class BatchEngine:
         for (w, b) in enc[:-1]:
             h = self.dense(h, t(w), t(b), _lib.ACT_TANH)
         w, b = enc[-1]
-        self.Z.copy_(self.dense(h, t(w), t(b), _lib.ACT_NONE))
+        mu = self.dense(h, t(w), t(b), _lib.ACT_NONE)        # (NT, L)
+        if self.L == LAT:
+            self.Z.copy_(mu)
+        else:                                                 # latent dimension 16: columns 16..31 are the zero padding
+            self.Z.zero_()
+            self.Z[:, :self.L].copy_(mu)
 
     def classify(self, clf, mean=None, std=None, eps=1e-8):
         """Labels from the classifier (scripts/evaluate_M2_vad.py:122-131): optional mean/std

@@ -80,8 +80,9 @@ class _MCEM:
         dev = torch.device(device if device not in (None, "cpu") else "cuda:0")
         N, F = X.shape
         L = getattr(vae, "latent_dim", None) or getattr(vae, "z_dim")
-        if L != LAT:
-            raise NotImplementedError("latent dim %d: this build supports %d" % (L, LAT))
+        if L not in (16, LAT):
+            raise NotImplementedError("latent dim %d: this build supports 16 and %d" % (L, LAT))
+        self._L = L
         ns_e, _ = self.e_step_counts()
         ns_w, _ = self.wf_counts()
         self.device, self.vae = dev, vae
@@ -96,7 +97,7 @@ class _MCEM:
             cap = N if (eng is None or self._eng_key != key) else max(N, 2 * eng._max_frames)
             if eng is not None:
                 eng.close()
-            eng = BatchEngine(F, nmf_rank, decoder_params_from_state(sd), precision=self.precision, device=dev, max_frames=cap, max_utts=1)
+            eng = BatchEngine(F, nmf_rank, decoder_params_from_state(sd), precision=self.precision, device=dev, max_frames=cap, max_utts=1, z_dim=L)
             self._enc, self._eng_key = _encoder_params(sd), key
         eng.bind([N], Rcap=max(ns_e, ns_w))
         self._eng, self._N, self._F, self._K = eng, N, F, nmf_rank
@@ -131,7 +132,7 @@ class _MCEM:
         return self._eng.g
     @property
     def Z(self):
-        return self._eng.Z.T
+        return self._eng.Z[:, :self._L].T
     @property
     def Vb(self):
         return self._eng.Vb(0)
@@ -154,10 +155,11 @@ class _MCEM:
         eps = u = None
         if self.rng == "replay":
             S = nsamples + burnin
-            e = torch.empty(S, N, LAT)
+            L = self._L
+            e = torch.zeros(S, N, LAT)                                         # (latent dim 16: columns 16..31 stay zero)
             uu = torch.empty(S, N)
             for m in range(S):                                                 # mcem.py:407, :420
-                e[m] = torch.randn(LAT, N).T
+                e[m, :, :L] = torch.randn(L, N).T
                 uu[m] = torch.rand(N)
             eps, u = e.to(self.device), uu.to(self.device)
         acc = eng.mh_chain(nsamples, burnin, self.var_RW, call=self._call, eps=eps, u=u, want_acc=want_acc,
@@ -236,7 +238,8 @@ class EM_noNMF(_MCEM):
         ns_e, _ = self.e_step_counts()
         ns_w, _ = self.wf_counts()
         self.device, self.vae = dev, vae
-        eng = BatchEngine(F, 1, decoder_params_from_state(sd), precision=precision, device=dev, max_frames=N, max_utts=1)
+        self._L = getattr(vae, "latent_dim", None) or getattr(vae, "z_dim")
+        eng = BatchEngine(F, 1, decoder_params_from_state(sd), precision=precision, device=dev, max_frames=N, max_utts=1, z_dim=self._L)
         eng.bind([N], Rcap=max(ns_e, ns_w))
         self._eng, self._N, self._F, self._K = eng, N, F, 1
         self.X = X.T                                                           # mcem.py:503
@@ -264,7 +267,8 @@ class MCEM_M2_noNMF(EM_noNMF):
         super().__init__(X, Vb, g, vae, niter, device, nsamples_E_step, burnin_E_step, nsamples_WF, burnin_WF, var_RW,
                          rng=rng, precision=precision)
         eng, N = self._eng, self._N
-        eng.Z.copy_(torch.as_tensor(Z, dtype=torch.float32).reshape(N, LAT))   # mcem.py:617
+        eng.Z.zero_()
+        eng.Z[:, :self._L].copy_(torch.as_tensor(Z, dtype=torch.float32).reshape(N, self._L))   # mcem.py:617
         yy = torch.as_tensor(y, dtype=torch.float32).to(self.device).reshape(N, -1).contiguous()
         eng.set_labels(yy)
         self.y = torch.t(yy)                                                   # mcem.py:618

@@ -8,7 +8,7 @@ import torch
 
 from . import stft as vstft
 from . import metrics as vmet
-from .engine import BatchEngine, decoder_params_from_state
+from .engine import BatchEngine, decoder_params_from_state, latent_dim_from_state
 from .mcem import _encoder_params
 
 
@@ -34,7 +34,7 @@ class Reconstructor:
             self.nsE, self.biE, self.nsW, self.biW = nsamples_E_step, burnin_E_step, nsamples_WF, burnin_WF
         self.device = torch.device(device)
         self.eng = BatchEngine(self.F, self.K, decoder_params_from_state(sd), precision=precision, device=device,
-                               max_frames=max_frames, max_utts=max_utts)
+                               max_frames=max_frames, max_utts=max_utts, z_dim=latent_dim_from_state(sd))
         self.model = model
 
     def enhance(self, wav, sample_counts, seeds=None, init_seed=0, y=None, classifier=None, mean=None, std=None):

@@ -12,7 +12,9 @@ state), Python lists and floats.  Any other global, reduce or opcode raises.
 
 Output (data only): tests/golden/stft_frames.npz -- int16 samples of utterance 440c020a (from its NIST SPHERE file:
 1024-byte ASCII header + little-endian PCM), the first and last 96 frames of its |STFT|^2 from the pickle, the
-frame counts of the three utterances; tests/golden/snr_db.npz -- the input-SNR lists.
+frame counts of the three utterances; tests/golden/stft_frames_tr_dt.npz -- the same for the reference's two other golden
+STFT outputs, si_tr_s_frames.p (513, 972) and si_dt_05_frames.p (513, 976): PCM of the first two utterances of each set and
+frames / per-frame sums of their |STFT|^2; tests/golden/snr_db.npz -- the input-SNR lists.
 Usage: python tests/golden/extract_ref_pickles.py
 """
 import os
@@ -152,6 +154,28 @@ def main():
                         head=np.ascontiguousarray(frames[:, :96]), tail=np.ascontiguousarray(frames[:, n0 - 96:n0]),
                         col_sums=frames[:, :n0].sum(0, dtype=np.float64), peak_b=np.abs(pcm[1][1600:]).max(), peak_c=np.abs(pcm[2][1600:]).max(),
                         first_b=np.ascontiguousarray(frames[:, n0:n0 + 4]))
+    # ---- the two other golden STFT outputs of the same reference test (train: si_tr_s/011, validation: si_dt_05/050):
+    # (513, 972) and (513, 976).  Per set: PCM of its first utterance, the first / last 48 frames and the per-frame sums of
+    # that utterance's |STFT|^2, the frame counts, and the first 4 frames + the peak of the second utterance.
+    extra = {}
+    for tag, sub, shape in (("tr", "si_tr_s", (513, 972)), ("dt", "si_dt_05", (513, 976))):
+        fr = read_plain_pickle(os.path.join(REF, "pickle/CSR-1-WSJ-0/%s_frames.p" % sub))
+        assert fr.shape == shape and fr.dtype == np.float32, (fr.shape, fr.dtype)
+        ws = sorted(os.path.join(dp, f) for dp, _, fs2 in os.walk(os.path.join(REF, "raw/CSR-1-WSJ-0/WAV/wsj0/" + sub)) for f in fs2 if f.endswith(".wav"))
+        pc = [read_sphere_pcm16(w) for w in ws]
+        cn = []
+        for x in pc:
+            T = len(x) - int(0.1 * fs)
+            pad = hop if int(np.ceil(T / fs / 64e-3 / 0.25)) != int(T / fs / 64e-3 / 0.25) else 0
+            cn.append(1 + (T + pad) // hop)
+        assert sum(cn) == fr.shape[1], (cn, fr.shape)
+        m0 = cn[0]
+        extra.update({tag + "_pcm_a": pc[0], tag + "_name_a": os.path.basename(ws[0]), tag + "_frame_counts": np.array(cn),
+                      tag + "_head": np.ascontiguousarray(fr[:, :48]), tag + "_tail": np.ascontiguousarray(fr[:, m0 - 48:m0]),
+                      tag + "_col_sums": fr[:, :m0].sum(0, dtype=np.float64), tag + "_pcm_b": pc[1],
+                      tag + "_first_b": np.ascontiguousarray(fr[:, m0:m0 + 4]), tag + "_col_sums_b": fr[:, m0:m0 + cn[1]].sum(0, dtype=np.float64)})
+        print(sub, "frames", fr.shape, "counts", cn, [os.path.basename(w) for w in ws])
+    np.savez_compressed(os.path.join(HERE, "stft_frames_tr_dt.npz"), **extra)
     out = {}
     for dp, _, fs_ in os.walk(REF):
         for f in fs_:

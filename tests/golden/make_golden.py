@@ -343,6 +343,14 @@ def spp_case():
     np.savez_compressed(os.path.join(HERE, "spp_f257.npz"), **out)
 
 
+def shapes_case():
+    """Decoder shapes beside 32 -> 128 -> 128 -> F that the reference's scripts list (scripts/evaluate_M1.py:44-85: z_dim 16,
+    h_dim [128]): full runs through the reference's generic classes (models.py:107-133) at those dims."""
+    run_case("m1_f65_z16", "M1", F=65, N=16, K=4, dims_h=[128, 128], L=16, niter=3, counts=(10, 6, 25, 8), seed=7)
+    run_case("m1_f65_h128", "M1", F=65, N=16, K=4, dims_h=[128], L=32, niter=3, counts=(10, 6, 25, 8), seed=11)
+    run_case("m2_vad_f65_z16_h128", "M2", F=65, N=16, K=4, dims_h=[128], L=16, niter=3, counts=(5, 7, 6, 9), Dy=1, seed=13)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:

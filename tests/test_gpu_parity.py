@@ -27,13 +27,16 @@ def need_gpu():
 
 
 def dec_list(params):
+    if "decoder.hidden.1.weight" not in params:          # one hidden layer (h_dim = [128])
+        return [params["decoder.hidden.0.weight"], params["decoder.hidden.0.bias"], params["decoder.reconstruction.weight"], params["decoder.reconstruction.bias"]]
     return [params["decoder.hidden.0.weight"], params["decoder.hidden.0.bias"], params["decoder.hidden.1.weight"],
             params["decoder.hidden.1.bias"], params["decoder.reconstruction.weight"], params["decoder.reconstruction.bias"]]
 
 
 def make_engine(params, F, K, counts_N, Rcap, precision="bf16x3", seeds=None):
     from vaenmf.engine import BatchEngine
-    eng = BatchEngine(F, K, dec_list(params), precision=precision, max_frames=sum(counts_N), max_utts=len(counts_N))
+    z_dim = int(params["encoder.sample.mu.weight"].shape[0]) if "encoder.sample.mu.weight" in params else 32
+    eng = BatchEngine(F, K, dec_list(params), precision=precision, max_frames=sum(counts_N), max_utts=len(counts_N), z_dim=z_dim)
     eng.bind(counts_N, Rcap=Rcap, seeds=seeds)
     return eng
 
@@ -88,22 +91,27 @@ def setup_from_case(name, model, precision="bf16x3"):
     eng.init_nmf([z["W0"]], [z["H0"]])
     if y is not None:
         eng.set_labels(torch.from_numpy(y))
-    eng.Z.copy_(torch.from_numpy(np.ascontiguousarray(z["Z0"].T)))
+    eng.Z.zero_()
+    eng.Z[:, :meta["L"]].copy_(torch.from_numpy(np.ascontiguousarray(z["Z0"].T)))
     return z, params, meta, o, rng, eng
 
 
 def replay_buffers(rng, S, N, L, dev):
-    """Take the next S (randn(L,N), rand(N)) pairs of the recorded stream."""
-    eps = np.empty((S, N, L), np.float32)
+    """Take the next S (randn(L,N), rand(N)) pairs of the recorded stream (a 16-dimensional latent space: the recorded
+    draws fill columns 0..15 of the engine's 32-wide rows, the padding columns stay zero)."""
+    eps = np.zeros((S, N, 32), np.float32)
     u = np.empty((S, N), np.float32)
     for m in range(S):
-        eps[m] = rng.draws[rng.pos].T
+        eps[m, :, :rng.draws[rng.pos].shape[0]] = rng.draws[rng.pos].T
         u[m] = rng.draws[rng.pos + 1]
         rng.pos += 2
     return torch.from_numpy(eps).to(dev), torch.from_numpy(u).to(dev)
 
 
-CASES = [("m1_f65", "M1"), ("m2_vad_f65", "M2"), ("m2_ibm_f65", "M2"), ("m1_f257", "M1")]
+CASES = [("m1_f65", "M1"), ("m2_vad_f65", "M2"), ("m2_ibm_f65", "M2"), ("m1_f257", "M1"),
+         # decoder shapes beside 32 -> 128 -> 128 -> F that the reference's scripts list (scripts/evaluate_M1.py:44-85): latent
+         # dimension 16 (zero-padded first layer, no random walk on the padding), ONE hidden layer (layer 2 skipped), both + M2
+         ("m1_f65_z16", "M1"), ("m1_f65_h128", "M1"), ("m2_vad_f65_z16_h128", "M2")]
 
 
 @pytest.mark.parametrize("name,model", CASES)
@@ -111,12 +119,12 @@ def test_encoder_init(name, model):
     """Z = mu_enc(|X|^2 [cat y]) (mcem.py:367-368 / :214-215) via vaenmf_dense."""
     need_gpu()
     z, params, meta, o, rng, eng = setup_from_case(name, model)
-    enc = [(params["encoder.hidden.0.weight"], params["encoder.hidden.0.bias"]),
-           (params["encoder.hidden.1.weight"], params["encoder.hidden.1.bias"]),
-           (params["encoder.sample.mu.weight"], params["encoder.sample.mu.bias"])]
+    enc = [(params["encoder.hidden.%d.weight" % i], params["encoder.hidden.%d.bias" % i]) for i in range(2) if "encoder.hidden.%d.weight" % i in params]
+    enc.append((params["encoder.sample.mu.weight"], params["encoder.sample.mu.bias"]))
     y = torch.from_numpy(z["y"]).to(eng.device) if model == "M2" else None
     eng.encode(enc, y)
-    assert np.max(np.abs(eng.Z.cpu().numpy().T - z["Z0"])) < 2e-5
+    L = meta["L"]
+    assert np.max(np.abs(eng.Z[:, :L].cpu().numpy().T - z["Z0"])) < 2e-5 and float(eng.Z[:, L:].abs().max() if L < 32 else 0.0) == 0.0
     assert rel_err(eng.X2[:, :meta["F"]].cpu().numpy().T, o.X_abs_2) < 1e-6
 
 
@@ -139,8 +147,10 @@ def test_first_em_iteration(name, model):
     # oracle chain on the same draws
     rng.pos = pos0
     Zs_ref = o.sample_posterior(o.Z, ns, bi)
-    assert np.max(np.abs(eng.Zs[:, :ns].cpu().numpy() - Zs_ref)) < 5e-6   # fma contraction of z + sd*eps
-    assert np.max(np.abs(eng.Z.cpu().numpy().T - z["E1_Z"])) < 1e-5
+    L = meta["L"]
+    assert np.max(np.abs(eng.Zs[:, :ns, :L].cpu().numpy() - Zs_ref)) < 5e-6   # fma contraction of z + sd*eps
+    assert L == 32 or float(eng.Zs[:, :ns, L:].abs().max()) == 0.0         # the padding latents never move
+    assert np.max(np.abs(eng.Z[:, :L].cpu().numpy().T - z["E1_Z"])) < 1e-5
     Vs = eng.decode(ns).cpu().numpy()[:, :, :F]                    # [N,R,F]
     assert rel_err(np.moveaxis(Vs, 0, -1), z["E1_Vs"]) < 2e-4
     # M-step
@@ -181,7 +191,7 @@ def test_full_run_replay(name, model):
     assert nrm_err(to_c(S), z["S_hat"]) < 2e-3
     assert nrm_err(to_c(Nn), z["N_hat"]) < 2e-3
     assert rel_err(WFs[:, :F].cpu().numpy().T, z["WFs"]) < 5e-3
-    assert np.max(np.abs(eng.Z.cpu().numpy().T - z["Z"])) < 1e-5
+    assert np.max(np.abs(eng.Z[:, :meta["L"]].cpu().numpy().T - z["Z"])) < 1e-5
     assert rel_err(eng.W[0, :F, :meta["K"]].cpu().numpy(), z["W"]) < 2e-3
     assert rel_err(eng.g.cpu().numpy(), z["g"]) < 2e-3
 
@@ -357,6 +367,15 @@ def test_stft_against_reference_known_answer():
     big = z["head"] > 1e-6 * scale
     assert np.max(np.abs(P[:, :96][big] / z["head"][big] - 1)) < 1e-5
     assert np.max(np.abs(P.sum(0, dtype=np.float64) / z["col_sums"] - 1)) < 1e-6
+
+
+def test_stft_against_the_reference_train_and_validation_known_answers():
+    """The HIP STFT against the reference's two other committed golden outputs (si_tr_s_frames.p, si_dt_05_frames.p;
+    tests/golden/stft_frames_tr_dt.npz): two utterances of each set, the bounds of the oracle's CPU test."""
+    need_gpu()
+    from vaenmf import stft as vstft
+    from test_oracle_golden import _check_stft_tr_dt
+    _check_stft_tr_dt(lambda x: vstft.stft(x, fs=16000, wlen_sec=64e-3, win="hann", hop_percent=0.25), 1e-5)
 
 
 @pytest.mark.parametrize("F,K,R,model", [(513, 10, 30, "M1"), (513, 32, 10, "M2"), (257, 32, 30, "M1"), (129, 16, 40, "M1")])
@@ -1147,3 +1166,74 @@ def test_fused_w_statistics_equal_the_two_kernel_path(R, counts):
     for x, y in zip(a, a2):
         assert np.array_equal(x, y)
     assert float(np.abs(a[0][:, F:]).max()) == 0.0 and float(np.abs(a[0][:, :, K:]).max()) == 0.0 if a[0].shape[2] > K else True
+
+
+def test_driver_and_metrics_on_all_nine_reference_utterances_ragged(tmp_path):
+    """Rows f1 / f2 on ALL the utterances the reference commits (data/subset/processed: si_tr_s/011, si_dt_05/050,
+    si_et_05/440, three each), cropped to NINE DIFFERENT lengths (tests/golden/processed_subset9.npz, made by
+    tests/golden/make_processed_subset.py): speech_list per subset in the reference's order
+    (python/dataset/csr1_wjs0_dataset.py:19-54), the evaluate_M1-style driver on one ragged batch of nine (bench mode:
+    bf16, sample store) and on batches of four, run_metrics per subset with the reference's own input-SNR lists, the
+    oracle's energy_ratios on the written files, and the 'oracle' IBM label source on the ragged batch."""
+    need_gpu()
+    from vaenmf import wavio, run_metrics
+    from vaenmf.driver import evaluate, speech_list
+    from vaenmf.pipeline import Reconstructor
+    from vaenmf import _lib
+    z = np.load(GOLDEN + "/processed_subset9.npz")
+    root = str(tmp_path) + "/"
+    raw, proc = root + "raw/", root + "processed/"
+    lens = {}
+    for i, rel in enumerate(z["rel"]):
+        rel = str(rel)
+        for base in (raw, proc):
+            os.makedirs(os.path.dirname(base + rel), exist_ok=True)
+        wavio.write(raw + rel, z["u%d_x" % i] / 32768.0, 16000)
+        for k in "snx":
+            wavio.write(proc + os.path.splitext(rel)[0] + "_%s.wav" % k, z["u%d_%s" % (i, k)] / 32768.0, 16000)
+        lens[rel] = len(z["u%d_x" % i])
+    assert len(set(lens.values())) == 9                                   # ragged: nine different lengths
+    files = []
+    for subset in ("train", "validation", "test"):
+        fl = speech_list(raw, subset)
+        assert fl == [str(r) for r, s in zip(z["rel"], z["subset"]) if str(s) == subset]
+        files += fl
+    F, K = 513, 10
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=0)
+    rec = Reconstructor(params, F, K, niter=4, fs=16000, wlen_sec=64e-3, precision="bf16", max_frames=1100, max_utts=9)
+    out9, out4 = root + "models/M1_b9/", root + "models/M1_b4/"
+    w9 = evaluate(rec, files, proc, out9, batch_size=16)
+    assert _lib.lib().vaenmf_plan_query(rec.eng._plan, _lib.Q_MSTEP_PATH) == 1
+    nfr = [1 + (lens[f] + (256 if lens[f] % 256 else 0)) // 256 for f in files]
+    assert list(rec.frame_counts) == nfr and len(set(nfr)) >= 8           # the batch the engine saw was ragged
+    w4 = evaluate(rec, files, proc, out4, batch_size=4)
+    assert len(w9) == len(w4) == 9
+    for (sa, na), fp in zip(w9, files):
+        a, fs = wavio.read(sa)
+        assert fs == 16000 and len(a) == lens[fp] == len(wavio.read(na)[0])
+        assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
+    assert np.array_equal(wavio.read(w9[0][0])[0], wavio.read(w4[0][0])[0])    # same seeds, same initialisation: first file
+    # run_metrics per subset against the oracle on the written files; per-SNR tables from the reference's own SNR lists
+    snr_z = np.load(GOLDEN + "/snr_db.npz")
+    for subset, key in (("validation", "processed__CSR-1-WSJ-0__si_dt_05_snr_db"), ("test", "processed__CSR-1-WSJ-0__si_et_05_snr_db")):
+        fl = speech_list(raw, subset)
+        snr = snr_z[key]
+        all_metrics, st = run_metrics.main(fl, proc, out9, snr)
+        for fp, m in zip(fl, all_metrics):
+            stem = os.path.splitext(fp)[0]
+            ref = orc.energy_ratios(wavio.read(out9 + stem + "_s_est.wav")[0], wavio.read(proc + stem + "_s.wav")[0], wavio.read(proc + stem + "_n.wav")[0])
+            assert np.max(np.abs(np.asarray(m) - np.asarray(ref))) < 1e-6
+        assert st[0, 0, 0] == 3 and st[1, 0, 0] == 1 and st[2, 0, 0] == 2      # all; SNR -5 dB: 1 utterance; the other bin: 2
+        assert abs(st[0, 0, 1] - sum(m[0] for m in all_metrics)) < 1e-9
+    mt = run_metrics.compute_metrics(speech_list(raw, "train"), proc, out9)
+    assert len(mt) == 3 and np.all(np.isfinite(np.asarray(mt)))
+    # 'oracle' IBM labels (evaluate_M2_ibm.py:132-134) on the ragged batch: exactly the oracle's labels per utterance
+    p2 = orc.xavier_normal_params([F, 32, [128, 128]], seed=1, y_dim=F)
+    rec2 = Reconstructor(p2, F, K, niter=2, model="M2", fs=16000, wlen_sec=64e-3, precision="bf16", max_frames=1100, max_utts=9)
+    evaluate(rec2, files, proc, root + "models/M2/", batch_size=16, label_source="oracle", label_type="ibm", quantile_fraction=0.999, quantile_weight=0.999)
+    for fp, n in zip(files, nfr):
+        stem = os.path.splitext(fp)[0]
+        hard = torch.load(root + "models/M2/" + stem + "_ibm_hard_est.pt", weights_only=True).numpy()
+        S = orc.stft(wavio.read(proc + stem + "_s.wav")[0], fs=16000, wlen_sec=64e-3)
+        assert hard.shape == (n, F) and np.array_equal(hard, orc.clean_speech_IBM(S, 0.999, 0.999).T)
+        assert np.all(np.isfinite(wavio.read(root + "models/M2/" + stem + "_s_est.wav")[0]))

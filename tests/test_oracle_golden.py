@@ -9,7 +9,8 @@ import pytest
 import vaenmf_oracle as orc
 from helpers import load_case, rel_err, nrm_err, GOLDEN
 
-CASES = [("m1_f65", "M1"), ("m2_vad_f65", "M2"), ("m2_ibm_f65", "M2"), ("m1_f257", "M1")]
+CASES = [("m1_f65", "M1"), ("m2_vad_f65", "M2"), ("m2_ibm_f65", "M2"), ("m1_f257", "M1"),
+         ("m1_f65_z16", "M1"), ("m1_f65_h128", "M1"), ("m2_vad_f65_z16_h128", "M2")]      # decoder shapes of scripts/evaluate_M1.py:44-85: z_dim 16, h_dim [128]
 
 
 def run_oracle(name, model):
@@ -207,3 +208,31 @@ def test_torch_cpu_restatement_full_run(name, model):
     for k, v in (("W", m.W), ("H", m.H), ("g", m.g)):
         assert rel_err(v.numpy(), z[k]) < 2e-4, k
     assert nrm_err(m.S_hat, z["S_hat"]) < 1e-5 and nrm_err(m.N_hat, z["N_hat"]) < 1e-5
+
+
+def _check_stft_tr_dt(stft_fn, tol_rel):
+    """The reference's two other golden STFT outputs (si_tr_s_frames.p (513, 972), si_dt_05_frames.p (513, 976): same test
+    recipe, tests/dataset/test_csr1_wjs0_dataset.py:17-83): first two utterances of each set."""
+    z = np.load(os.path.join(GOLDEN, "stft_frames_tr_dt.npz"))
+    for tag in ("tr", "dt"):
+        cn = z[tag + "_frame_counts"]
+        for which, n_fr in (("a", int(cn[0])), ("b", int(cn[1]))):
+            x = z["%s_pcm_%s" % (tag, which)].astype(np.float64) / 32768.0
+            x = x[int(0.1 * 16000):]
+            x = x / np.max(np.abs(x))
+            P = np.power(np.abs(stft_fn(x)), 2)
+            assert P.shape == (513, n_fr), (tag, which, P.shape)
+            if which == "a":
+                head, tail, cs = z[tag + "_head"], z[tag + "_tail"], z[tag + "_col_sums"]
+                scale = np.max(head)
+                assert np.max(np.abs(P[:, :48] - head)) < 2e-7 * scale and np.max(np.abs(P[:, n_fr - 48:] - tail)) < 2e-7 * max(scale, np.max(tail))
+                big = head > 1e-6 * scale
+                assert np.max(np.abs(P[:, :48][big] / head[big] - 1)) < tol_rel
+            else:
+                fb, cs = z[tag + "_first_b"], z[tag + "_col_sums_b"]
+                assert np.max(np.abs(P[:, :4] - fb)) < 2e-7 * max(np.max(fb), 1e-30) + 1e-12
+            assert np.max(np.abs(P.sum(0, dtype=np.float64) / cs - 1)) < 1e-6
+
+
+def test_stft_against_the_reference_train_and_validation_known_answers():
+    _check_stft_tr_dt(lambda x: orc.stft(x, fs=16000, wlen_sec=64e-3, win="hann", hop_percent=0.25), 5e-6)
