@@ -246,7 +246,7 @@ __device__ __forceinline__ Xs128 xs_seed(uint64_t utt_seed, uint32_t frame, uint
 // 2^-16 grid, |eps| <= 4.71 sigma, changes nothing the sampler's distribution can show; any symmetric proposal leaves
 // the Metropolis-Hastings target unchanged).
 #ifndef VN_RNG16
-#define VN_RNG16 0
+#define VN_RNG16 1
 #endif
 __device__ __forceinline__ f32x4 normal4(Xs128& st) {
   f32x4 o;

@@ -241,3 +241,26 @@ def test_wave_chain_addressability_guard():
     assert f(280_000, 75, 105, 272, 8, 500, 0) == 1                     # the device generator needs no draw buffer
     # spectrogram rows [NT][Fs] float at the widest supported row
     assert f(1_400_000, 1, 2, 640, 8, 2000, 0) == 1 and f(1_500_000, 1, 2, 640, 8, 2000, 0) == 0
+
+
+def test_committed_traffic_profiles_name_every_kernel_the_bench_reports():
+    """bench.py reads the HBM bytes per launch of the dominant kernels from the committed rocprofv3 PMC summaries
+    (profiles/round*_<tag>_traffic.json).  A renamed kernel must fail HERE, not silently drop a field of the bench line:
+    every workload the bench reports has a round-3 profile whose kernels include the chain, the W statistics, the W
+    update and the H/g kernel."""
+    import json
+    prof = os.path.join(ROOT, "profiles")
+    need = {"bf16": ("chain_kernel", "wstats_fused", "w_update_tiles", "hg_stream"),
+            "bf16x3": ("chain_kernel", "wstats_stream", "w_update", "hg_stream"),
+            "bf16_M2ibm_f257_k8": ("chain_kernel", "wstats_fused", "w_update_tiles", "hg_stream"),
+            "bf16_M2vad_f257_k8": ("chain_kernel", "wstats_fused", "w_update_tiles", "hg_stream"),
+            "bf16_M1_f513_k10": ("chain_kernel", "wstats_stream", "w_update", "hg_stream"),
+            "bf16_M1_f513_k32": ("chain_kernel", "wstats_stream", "w_update", "hg_stream")}
+    for tag, subs in need.items():
+        fn = os.path.join(prof, "round3_%s_traffic.json" % tag)
+        assert os.path.exists(fn), fn
+        kern = json.load(open(fn))["kernels"]
+        for sub in subs:
+            hit = [v for k, v in kern.items() if sub in k]
+            assert hit and hit[0]["hbm_bytes_per_launch"] > 0 and hit[0]["launches"] > 0, (tag, sub)
+        assert os.path.exists(os.path.join(prof, "round3_%s_summary.txt" % tag))

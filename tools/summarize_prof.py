@@ -10,7 +10,8 @@ def short(k):
     return k[:90]
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)      # (gpurun merges into an existing directory: take the latest run)
 st = newest(os.path.join(src, "trace/*/*_kernel_stats.csv"))
-P("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --precision", tag)
+cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "python bench.py --precision " + tag
+P("# rocprofv3 --kernel-trace --stats -- %s --steps 2 --warmup 1   [workload tag: %s]" % (cmd, tag))
 P("# (per kernel: calls, total ms, average us, % of GPU kernel time)")
 for r in csv.DictReader(open(st)):
     P("%-92s calls %6s  total %10.3f ms  avg %10.2f us  %6s %%" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
@@ -32,7 +33,7 @@ P("# HBM traffic (separate --pmc passes, niter=10): FETCH_SIZE and WRITE_SIZE ar
 P("# MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads on gfx950 -> doubled below")
 fa, fn, _ = pmc("pmc_fetch"); wa, wn, _ = pmc("pmc_write")
 for k in fa:
-    if not any(s in k for s in ("chain_kernel", "decode_kernel", "stream_kernel", "stream2_kernel", "rot_kernel", "w_update", "w_partial")): continue
+    if not any(s in k for s in ("chain_kernel", "decode_kernel", "stream_kernel", "stream2_kernel", "rot_kernel", "fused_kernel", "w_update", "w_partial")): continue
     n = len(fn[k]); f = fa[k]["FETCH_SIZE"] / n; w = wa.get(k, {}).get("WRITE_SIZE", 0.0) / max(len(wn.get(k, [1])), 1)
     P("%-92s launches %4d  FETCH_SIZE/launch %10.1f KB (x2 = %8.2f MB)  WRITE_SIZE/launch %10.1f KB  => HBM %8.2f MB/launch"
       % (k, n, f, 2 * f / 1024, w, (2 * f + w) / 1024))
@@ -40,14 +41,14 @@ traffic = {}
 for k in fa:
     n = len(fn[k]); f = fa[k]["FETCH_SIZE"] / n; w = wa.get(k, {}).get("WRITE_SIZE", 0.0) / max(len(wn.get(k, [1])), 1)
     traffic[k] = {"fetch_size_kb_raw": f, "write_size_kb": w, "hbm_bytes_per_launch": (2 * f + w) * 1024, "launches": n}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --niter 10 --precision " + tag,
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- %s --steps 1 --warmup 0 --niter 10" % cmd,
            "correction": "FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md); units of 1 KiB",
            "kernels": traffic}, open(os.path.join(os.path.dirname(out), "%s_%s_traffic.json" % (rnd, tag)), "w"), indent=1)
 P("")
 P("# SQ counters (niter=10), summed over launches; *_CYCLES of waves are quad-cycles, VALU_MFMA_BUSY in cycles")
 sa, sn, _ = pmc("pmc_sq")
 for k in sa:
-    if not any(s in k for s in ("chain_kernel", "decode_kernel", "stream_kernel", "stream2_kernel", "rot_kernel")): continue
+    if not any(s in k for s in ("chain_kernel", "decode_kernel", "stream_kernel", "stream2_kernel", "rot_kernel", "fused_kernel")): continue
     v = sa[k]; wc = v["SQ_WAVE_CYCLES"]
     P("%-92s launches %d" % (k, len(sn[k])))
     for c in sorted(v): P("    %-28s %16.0f   (%.3f of SQ_WAVE_CYCLES)" % (c, v[c], v[c] / wc))
@@ -56,7 +57,7 @@ try:
     P("")
     P("# second SQ pass (niter=10), per launch")
     for k in s2:
-        if not any(s in k for s in ("chain_kernel", "stream_kernel", "stream2_kernel", "rot_kernel")): continue
+        if not any(s in k for s in ("chain_kernel", "stream_kernel", "stream2_kernel", "rot_kernel", "fused_kernel")): continue
         P("%-92s launches %d" % (k, len(s2n[k])))
         for c in sorted(s2[k]): P("    %-28s %16.0f per launch" % (c, s2[k][c] / len(s2n[k])))
 except Exception as e:
