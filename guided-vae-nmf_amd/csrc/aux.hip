@@ -146,21 +146,23 @@ __global__ __launch_bounds__(640) void w_update_tiles_kernel(const float* __rest
   }
 }
 
-// cost[u][it] = mean_{r,f,n}(log Vx + X2/Vx)  (mcem.py:70) from per-frame sums
-__global__ void cost_reduce_kernel(const double* __restrict__ cost_frames, const int32_t* __restrict__ frame_off,
-                                   int R, int F, double* __restrict__ cost, int niter, int it) {
+// cost[u][it] = mean_{r,f,n}(log Vx + X2/Vx)  (mcem.py:70) from per-frame sums; block (u, j): iteration it0 + j, whose
+// per-frame sums are row j of cost_frames [n_it][stride]
+__global__ void cost_reduce_kernel(const double* __restrict__ cost_frames, size_t stride, const int32_t* __restrict__ frame_off,
+                                   int R, int F, double* __restrict__ cost, int niter, int it0) {
   __shared__ double red[256];
-  const int u = blockIdx.x;
+  const int u = blockIdx.x, j = blockIdx.y;
   const int nb = frame_off[u], ne = frame_off[u + 1];
+  const double* cf = cost_frames + (size_t)j * stride;
   double s = 0.0;
-  for (int n = nb + threadIdx.x; n < ne; n += blockDim.x) s += cost_frames[n];
+  for (int n = nb + threadIdx.x; n < ne; n += blockDim.x) s += cf[n];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int m = 128; m >= 1; m >>= 1) {
     if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
     __syncthreads();
   }
-  if (threadIdx.x == 0) cost[(size_t)u * niter + it] = red[0] / ((double)R * F * (ne - nb));
+  if (threadIdx.x == 0) cost[(size_t)u * niter + it0 + j] = red[0] / ((double)R * F * (ne - nb));
 }
 
 // ----------------------------------------------------------------------------
@@ -406,8 +408,9 @@ int vn_launch_w_update_tiles(const vaenmf_plan* p, float* W, hipStream_t st) {
   return 0;
 }
 
-int vn_launch_cost_reduce(const vaenmf_plan* p, const double* cost_frames, int R, double* cost, int niter, int it, hipStream_t st) {
-  hipLaunchKernelGGL(cost_reduce_kernel, dim3(p->n_utt), dim3(256), 0, st, cost_frames, p->d_frame_off, R, p->cfg.F, cost, niter, it);
+// n_it consecutive iterations it0 .. it0 + n_it - 1 in one launch (cost_frames: n_it rows of `stride` doubles)
+int vn_launch_cost_reduce(const vaenmf_plan* p, const double* cost_frames, size_t stride, int n_it, int R, double* cost, int niter, int it0, hipStream_t st) {
+  hipLaunchKernelGGL(cost_reduce_kernel, dim3(p->n_utt, n_it), dim3(256), 0, st, cost_frames, stride, p->d_frame_off, R, p->cfg.F, cost, niter, it0);
   VN_CHECK_HIP(hipGetLastError());
   return 0;
 }

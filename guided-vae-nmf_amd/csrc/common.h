@@ -29,6 +29,7 @@ void vaenmf_set_error(const char* fmt, ...);
     }                                        \
   } while (0)
 
+constexpr int VN_COST_CHUNK = 25;     // EM iterations whose per-frame cost sums the fused driver keeps before one reduction launch
 constexpr int MAX_TILE_FRAMES = 64;   // MH chain: frames per workgroup = 32 per team (2 MFMA column groups of 16)
 constexpr int LAT = 32;               // latent dimension handled by the MFMA path
 constexpr int HID = 128;              // hidden width of both decoder layers
@@ -76,7 +77,7 @@ struct vaenmf_plan {
   float *A1, *P;             // [NT][Fs] W-update statistics
   float* normW;              // [n_utt][Kp]
   float* wpart;              // [n_utt][8 chunks][Fs][2 Kp] partial W-update sums
-  double* cost_frames;       // [NT] (fused driver)
+  double* cost_frames;       // [VN_COST_CHUNK][max_frames] per-frame cost sums of the fused driver (a row per iteration of a chunk)
   // sample-variance store (vaenmf_sample_store): the MH chain keeps the decoded variances of its samples here
   bool store_on;
   void* VsS;                 // [NT][store_Rs][Fs], float (bf16x3 mode) or bf16 (bf16 mode)

@@ -1423,7 +1423,7 @@ bool vn_wchain_fits(const vaenmf_plan* p, const VnChainCall& cc);
 int vn_launch_wchain(vaenmf_plan* p, const VnChainCall& cc, hipStream_t st);
 // aux.hip
 int vn_launch_w_update(const vaenmf_plan* p, float* W, const float* Ht, hipStream_t st);
-int vn_launch_cost_reduce(const vaenmf_plan* p, const double* cost_frames, int R, double* cost, int niter, int it, hipStream_t st);
+int vn_launch_cost_reduce(const vaenmf_plan* p, const double* cost_frames, size_t stride, int n_it, int R, double* cost, int niter, int it0, hipStream_t st);
 
 extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, const float* Ht, const float* g,
                                float* Z, int32_t update_Z, const float* B1, float* Zs, int32_t Rcap, int32_t nsamples,
@@ -1593,12 +1593,19 @@ static int em_run_body(vaenmf_plan* p, const float* X2, float* W, float* Ht, flo
                        const float* X, float* S_hat, float* N_hat, double* cost, bool stored, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   vaenmf_rng rng = {VAENMF_RNG_DEVICE, 0, nullptr, nullptr};
+  // the per-frame cost sums of VN_COST_CHUNK iterations are kept (one row of the plan's cost buffer each) and reduced to
+  // cost[u][it] by ONE launch per chunk instead of one per iteration
+  const size_t cstride = (size_t)p->cfg.max_frames;
   for (int it = 0; it < niter; ++it) {                  // EM.run, mcem.py:159-165
     rng.call = (uint32_t)it;
+    double* cf = p->cost_frames + (size_t)(it % VN_COST_CHUNK) * cstride;
     if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, 1, B1, Zs, Rcap, nsE, biE, var_rw, &rng, nullptr, stream)) return e;
-    if (int e = stored ? vaenmf_m_step_stored(p, X2, W, Ht, g, p->cost_frames, stream)
-                       : vaenmf_m_step(p, X2, W, Ht, g, Zs, Rcap, nsE, B1, p->cost_frames, stream)) return e;
-    if (cost) if (int e2 = vn_launch_cost_reduce(p, p->cost_frames, nsE, cost, niter, it, st)) return e2;
+    if (int e = stored ? vaenmf_m_step_stored(p, X2, W, Ht, g, cf, stream)
+                       : vaenmf_m_step(p, X2, W, Ht, g, Zs, Rcap, nsE, B1, cf, stream)) return e;
+    if (cost && ((it + 1) % VN_COST_CHUNK == 0 || it + 1 == niter)) {
+      const int it0 = it - it % VN_COST_CHUNK;
+      if (int e2 = vn_launch_cost_reduce(p, p->cost_frames, cstride, it - it0 + 1, nsE, cost, niter, it0, st)) return e2;
+    }
   }
   rng.call = (uint32_t)niter;                           // compute_WF(sample=True), mcem.py:173
   if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, 0, B1, Zs, Rcap, nsWF, biWF, var_rw, &rng, nullptr, stream)) return e;

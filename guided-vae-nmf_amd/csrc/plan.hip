@@ -159,7 +159,7 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   e |= dev_alloc(&p->P, NTc * p->Fs);
   e |= dev_alloc(&p->normW, Uc * p->Kp);
   e |= dev_alloc(&p->wpart, Uc * 8 * p->Fs * 2 * p->Kp);
-  e |= dev_alloc(&p->cost_frames, NTc);
+  e |= dev_alloc(&p->cost_frames, NTc * VN_COST_CHUNK);
   const size_t max_t64 = NTc / 64 + Uc + 1;
   e |= dev_alloc(&p->d_t64_n0, max_t64);
   e |= dev_alloc(&p->d_t64_cnt, max_t64);
