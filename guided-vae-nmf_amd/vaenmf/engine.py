@@ -39,6 +39,33 @@ def decoder_params_from_state(sd, prefix="decoder."):
             get("reconstruction.weight"), get("reconstruction.bias")]
 
 
+def classifier_layers_from_state(sd, two_classes=False, bn_eps=1e-5):
+    """[(W, b) hidden..., (W, b) output] for BatchEngine.classify / pipeline.MaskEnhancer from a Classifier state_dict
+    (models.py:41-62: `hidden.{i}.*`, `output_layer.*`).  With batch_norm=True the ModuleList alternates Linear and
+    BatchNorm1d and the reference applies relu to EVERY module (relu(BN(relu(Linear))), models.py:50-52, 59-60): in eval mode
+    (scripts/reconstruct_dnn_classif.py:129) a BatchNorm1d is the per-feature affine s = gamma / sqrt(running_var + eps),
+    t = beta - running_mean * s, handed to the dense kernel as one more ReLU layer with a diagonal weight.
+    two_classes: Classifier2Classes (models.py:64-88): softmax over the two classes of output_layer(x).view(-1, 2, y_dim);
+    the returned output layer is (W[:y] - W[y:], b[:y] - b[y:]), whose sigmoid is the class-0 probability (class 1 = 1 - it)."""
+    get = lambda k: _np32(sd[k].detach().cpu().numpy() if hasattr(sd[k], "detach") else sd[k])
+    layers, i = [], 0
+    while "hidden.%d.weight" % i in sd:
+        w = get("hidden.%d.weight" % i)
+        if w.ndim == 2:
+            layers.append((w, get("hidden.%d.bias" % i)))
+        else:
+            s_ = w.astype(np.float64) / np.sqrt(get("hidden.%d.running_var" % i).astype(np.float64) + bn_eps)
+            t_ = get("hidden.%d.bias" % i).astype(np.float64) - get("hidden.%d.running_mean" % i).astype(np.float64) * s_
+            layers.append((_np32(np.diag(s_)), _np32(t_)))
+        i += 1
+    wo, bo = get("output_layer.weight"), get("output_layer.bias")
+    if two_classes:
+        y = wo.shape[0] // 2
+        wo, bo = _np32(wo[:y].astype(np.float64) - wo[y:].astype(np.float64)), _np32(bo[:y].astype(np.float64) - bo[y:].astype(np.float64))
+    layers.append((wo, bo))
+    return layers
+
+
 def latent_dim_from_state(sd):
     """z_dim of a model from its state_dict (encoder.sample.mu.weight is (z_dim, h))."""
     return int(sd["encoder.sample.mu.weight"].shape[0])

@@ -118,3 +118,27 @@ class Classifier(nn.Module):
         for layer in self.hidden:
             x = torch.relu(layer(x))
         return torch.sigmoid(self.output_layer(x))
+
+
+class Classifier2Classes(nn.Module):
+    """models.py:64-88: the Classifier with 2 * y_dim outputs and a softmax over the two classes; forward returns
+    (N, 2, y_dim).  (vaenmf.engine.classifier_layers_from_state(sd, two_classes=True) gives the HIP path's layers.)"""
+
+    def __init__(self, dims, batch_norm=False):
+        super().__init__()
+        x_dim, h_dim, y_dim = dims
+        neurons = [x_dim, *h_dim]
+        layers = []
+        for i in range(1, len(neurons)):
+            layers.append(nn.Linear(neurons[i - 1], neurons[i]))
+            if batch_norm:
+                layers.append(nn.BatchNorm1d(neurons[i]))
+        self.hidden = nn.ModuleList(layers)
+        self.output_layer = nn.Linear(h_dim[-1], 2 * y_dim)
+        self.softmax = nn.Softmax(dim=1)
+        self.y_dim = y_dim
+
+    def forward(self, x):
+        for layer in self.hidden:
+            x = torch.relu(layer(x))
+        return self.softmax(self.output_layer(x).view(-1, 2, self.y_dim))

@@ -113,15 +113,26 @@ def decoder_forward(params, z):
                          params["decoder.reconstruction.bias"]))
 
 
-def classifier_forward(params, x):
-    """Classifier.forward (models.py:57-62), batch_norm=False: relu* -> sigmoid."""
+def classifier_forward(params, x, two_classes=False, bn_eps=1e-5):
+    """Classifier.forward (models.py:57-62): relu(layer) for EVERY module of `hidden` -- Linear and, with batch_norm=True,
+    the BatchNorm1d behind it (models.py:50-52: relu(BN(relu(Linear)))), in eval mode (running statistics, as
+    scripts/reconstruct_dnn_classif.py:129 runs it) -- then sigmoid(output_layer).  two_classes: Classifier2Classes
+    (models.py:64-88): softmax over the two classes of output_layer(x).view(-1, 2, y_dim); returns (N, 2, y_dim)."""
     h = np.asarray(x, dtype=f32)
     i = 0
     while "hidden.%d.weight" % i in params:
-        h = np.maximum(linear(h, params["hidden.%d.weight" % i],
-                              params["hidden.%d.bias" % i]), f32(0))
+        w = params["hidden.%d.weight" % i]
+        if w.ndim == 2:
+            h = np.maximum(linear(h, w, params["hidden.%d.bias" % i]), f32(0))
+        else:                                  # BatchNorm1d, eval mode
+            inv = f32(1) / np.sqrt(params["hidden.%d.running_var" % i].astype(f32) + f32(bn_eps))
+            h = np.maximum((h - params["hidden.%d.running_mean" % i].astype(f32)) * inv * w.astype(f32) + params["hidden.%d.bias" % i].astype(f32), f32(0))
         i += 1
     o = linear(h, params["output_layer.weight"], params["output_layer.bias"])
+    if two_classes:
+        o = o.reshape(o.shape[0], 2, -1)
+        e = np.exp(o - o.max(1, keepdims=True))
+        return (e / e.sum(1, keepdims=True)).astype(f32)
     return (f32(1) / (f32(1) + np.exp(-o))).astype(f32)
 
 

@@ -343,6 +343,42 @@ def spp_case():
     np.savez_compressed(os.path.join(HERE, "spp_f257.npz"), **out)
 
 
+def classifier_variants_case():
+    """Classifier(batch_norm=True) in eval mode (scripts/reconstruct_dnn_classif.py:80,125-129) and Classifier2Classes
+    (models.py:64-88): forwards of the reference classes on seeded weights and non-trivial running statistics."""
+    F, N, Dy = 129, 24, 5
+    g = np.random.default_rng(21)
+    out = {}
+    x = g.standard_normal((N, F)).astype(np.float32)
+    clf = ref_models.Classifier([F, [128, 128], Dy], batch_norm=True)
+    sd = {}
+    for k, v in clf.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.tensor(7)
+        elif "running_var" in k:
+            sd[k] = torch.tensor((0.5 + g.random(tuple(v.shape))).astype(np.float32))
+        elif "running_mean" in k:
+            sd[k] = torch.tensor((0.3 * g.standard_normal(tuple(v.shape))).astype(np.float32))
+        elif v.ndim == 1 and k.startswith("hidden") and int(k.split(".")[1]) % 2 == 1 and k.endswith("weight"):
+            sd[k] = torch.tensor((0.5 + g.random(tuple(v.shape))).astype(np.float32))          # BN gamma
+        else:
+            sd[k] = torch.tensor((g.standard_normal(tuple(v.shape)) * (0.1 if v.ndim == 1 else 1.0 / np.sqrt(v.shape[-1]))).astype(np.float32))
+    clf.load_state_dict(sd); clf.eval()
+    with torch.no_grad():
+        out["bn_y"] = clf(torch.tensor(x)).numpy()
+    out.update({"bn:p:" + k: v.numpy() for k, v in sd.items()})
+    c2 = ref_models.Classifier2Classes([F, [128, 128], Dy])
+    sd2 = {k: torch.tensor((g.standard_normal(tuple(v.shape)) * (0.1 if v.ndim == 1 else 1.0 / np.sqrt(v.shape[-1]))).astype(np.float32))
+           for k, v in c2.state_dict().items()}
+    c2.load_state_dict(sd2); c2.eval()
+    with torch.no_grad():
+        out["c2_y"] = c2(torch.tensor(x)).numpy()
+    out.update({"c2:p:" + k: v.numpy() for k, v in sd2.items()})
+    out["x"] = x
+    np.savez_compressed(os.path.join(HERE, "mlp_forward_variants.npz"), **out)
+    print("mlp_forward_variants:", out["bn_y"].shape, out["c2_y"].shape)
+
+
 def shapes_case():
     """Decoder shapes beside 32 -> 128 -> 128 -> F that the reference's scripts list (scripts/evaluate_M1.py:44-85: z_dim 16,
     h_dim [128]): full runs through the reference's generic classes (models.py:107-133) at those dims."""

@@ -1237,3 +1237,26 @@ def test_driver_and_metrics_on_all_nine_reference_utterances_ragged(tmp_path):
         S = orc.stft(wavio.read(proc + stem + "_s.wav")[0], fs=16000, wlen_sec=64e-3)
         assert hard.shape == (n, F) and np.array_equal(hard, orc.clean_speech_IBM(S, 0.999, 0.999).T)
         assert np.all(np.isfinite(wavio.read(root + "models/M2/" + stem + "_s_est.wav")[0]))
+
+
+def test_classifier_batch_norm_and_two_class_on_the_device():
+    """Classifier(batch_norm=True) (eval mode: relu(BN(relu(Linear))), models.py:50-52, scripts/reconstruct_dnn_classif.py:
+    80, 125-129) and Classifier2Classes (models.py:64-88) through vaenmf_dense with the layers
+    vaenmf.engine.classifier_layers_from_state folds, against forwards of the reference classes
+    (tests/golden/mlp_forward_variants.npz): soft outputs 1e-5."""
+    need_gpu()
+    from vaenmf import _lib
+    from vaenmf.engine import classifier_layers_from_state
+    z = np.load(GOLDEN + "/mlp_forward_variants.npz")
+    params = orc.xavier_normal_params([129, 32, [128, 128]], seed=3)
+    eng = make_engine(params, 129, 4, [z["x"].shape[0]], Rcap=4)
+    dev = eng.device
+    for tag, two, want in (("bn", False, z["bn_y"]), ("c2", True, z["c2_y"][:, 0, :])):
+        p = {k.split(":p:")[1]: z[k] for k in z.files if k.startswith(tag + ":p:")}
+        layers = classifier_layers_from_state(p, two_classes=two)
+        h = torch.from_numpy(z["x"]).to(dev)
+        for w, b in layers[:-1]:
+            h = eng.dense(h, torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev), _lib.ACT_RELU)
+        w, b = layers[-1]
+        y = eng.dense(h, torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev), _lib.ACT_SIGMOID).cpu().numpy()
+        assert y.shape == want.shape and np.max(np.abs(y - want)) < 1e-5, tag

@@ -236,3 +236,34 @@ def _check_stft_tr_dt(stft_fn, tol_rel):
 
 def test_stft_against_the_reference_train_and_validation_known_answers():
     _check_stft_tr_dt(lambda x: orc.stft(x, fs=16000, wlen_sec=64e-3, win="hann", hop_percent=0.25), 5e-6)
+
+
+def test_classifier_batch_norm_and_two_class_forwards():
+    """Classifier(batch_norm=True) in eval mode and Classifier2Classes (models.py:41-88) against forwards of the reference
+    classes (tests/golden/mlp_forward_variants.npz): the oracle's restatement, the mirror torch modules (same state_dict
+    keys), and the folded layer list the HIP path runs (vaenmf.engine.classifier_layers_from_state) evaluated in numpy."""
+    import torch
+    import vaenmf
+    from vaenmf.engine import classifier_layers_from_state
+    z = np.load(os.path.join(GOLDEN, "mlp_forward_variants.npz"))
+    pb = {k.split(":p:")[1]: z[k] for k in z.files if k.startswith("bn:p:")}
+    p2 = {k.split(":p:")[1]: z[k] for k in z.files if k.startswith("c2:p:")}
+    x = z["x"]
+    assert np.max(np.abs(orc.classifier_forward(pb, x) - z["bn_y"])) < 1e-6
+    assert np.max(np.abs(orc.classifier_forward(p2, x, two_classes=True) - z["c2_y"])) < 1e-6
+    m = vaenmf.Classifier([129, [128, 128], 5], batch_norm=True)
+    m.load_state_dict({k: torch.tensor(v) for k, v in pb.items()}); m.eval()
+    m2 = vaenmf.Classifier2Classes([129, [128, 128], 5])
+    m2.load_state_dict({k: torch.tensor(v) for k, v in p2.items()}); m2.eval()
+    with torch.no_grad():
+        assert np.max(np.abs(m(torch.tensor(x)).numpy() - z["bn_y"])) < 1e-6
+        assert np.max(np.abs(m2(torch.tensor(x)).numpy() - z["c2_y"])) < 1e-6
+
+    def run(layers):
+        h = x.astype(np.float64)
+        for w, b in layers[:-1]:
+            h = np.maximum(h @ w.astype(np.float64).T + b, 0)
+        w, b = layers[-1]
+        return 1 / (1 + np.exp(-(h @ w.astype(np.float64).T + b)))
+    assert np.max(np.abs(run(classifier_layers_from_state(pb)) - z["bn_y"])) < 2e-6
+    assert np.max(np.abs(run(classifier_layers_from_state(p2, two_classes=True)) - z["c2_y"][:, 0, :])) < 2e-6
