@@ -15,10 +15,15 @@ namespace {
 // ----------------------------------------------------------------------------
 constexpr int W_NCH = 8;
 
+// Ranks are independent in the update (the column norms are per rank): w_update_kernel splits the padded ranks above 8
+// over blockIdx.y in groups of KG = 8 -- one workgroup per utterance before, 64 workgroups on 256 CUs; rank 32: 56 -> 21 us.
+constexpr int W_KG = 8;
+
 template <int KP>
 __global__ __launch_bounds__(640) void w_partial_kernel(const float* __restrict__ A1, const float* __restrict__ P,
                                                         const float* __restrict__ Ht, float* __restrict__ part,
                                                         const int32_t* __restrict__ frame_off, int Fs) {
+  // (not split over rank groups: every group would read the A1 / P rows again -- measured 64 -> 71 us at rank 32)
   const int u = blockIdx.y, ch = blockIdx.x, f = threadIdx.x;
   const int nb = frame_off[u], ne = frame_off[u + 1];
   const int per = (ne - nb + W_NCH - 1) / W_NCH;
@@ -27,7 +32,7 @@ __global__ __launch_bounds__(640) void w_partial_kernel(const float* __restrict_
 #pragma unroll
   for (int k = 0; k < KP; ++k) num[k] = den[k] = 0.f;
   if (f < Fs) {
-#pragma unroll 4
+#pragma unroll 8
     for (int n = n0; n < n1; ++n) {
       const float pv = P[(size_t)n * Fs + f], av = A1[(size_t)n * Fs + f];
 #pragma unroll
@@ -49,51 +54,51 @@ __global__ __launch_bounds__(640) void w_partial_kernel(const float* __restrict_
 template <int KP>
 __global__ __launch_bounds__(640) void w_update_kernel(const float* __restrict__ part, float* __restrict__ W,
                                                        float* __restrict__ normW, int F, int Fs, int K) {
-  __shared__ float colred[10][KP];
-  const int u = blockIdx.x, f = threadIdx.x;
-  float wn[KP];
+  __shared__ float colred[10][W_KG];
+  const int u = blockIdx.x, f = threadIdx.x, k0 = blockIdx.y * W_KG;
+  float wn[W_KG];
 #pragma unroll
-  for (int k = 0; k < KP; ++k) wn[k] = 0.f;
+  for (int k = 0; k < W_KG; ++k) wn[k] = 0.f;
   if (f < F) {
-    float num[KP], den[KP];
+    float num[W_KG], den[W_KG];
 #pragma unroll
-    for (int k = 0; k < KP; ++k) num[k] = den[k] = 0.f;
+    for (int k = 0; k < W_KG; ++k) num[k] = den[k] = 0.f;
     for (int ch = 0; ch < W_NCH; ++ch) {                 // fixed order: deterministic
       const float* src = part + (((size_t)u * W_NCH + ch) * Fs + f) * 2 * KP;
 #pragma unroll
-      for (int k = 0; k < KP; k += 4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(src + k), b = *reinterpret_cast<const f32x4*>(src + KP + k);
+      for (int k = 0; k < W_KG; k += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + k0 + k), b = *reinterpret_cast<const f32x4*>(src + KP + k0 + k);
 #pragma unroll
         for (int t = 0; t < 4; ++t) { num[k + t] += a[t]; den[k + t] += b[t]; }
       }
     }
 #pragma unroll
-    for (int k = 0; k < KP; ++k)
-      if (k < K) wn[k] = W[((size_t)u * Fs + f) * KP + k] * sqrtf(num[k] / den[k]);          // mcem.py:110
+    for (int k = 0; k < W_KG; ++k)
+      if (k0 + k < K) wn[k] = W[((size_t)u * Fs + f) * KP + k0 + k] * sqrtf(num[k] / den[k]);          // mcem.py:110
   }
   // column L1 norms (mcem.py:129): DPP/permlane wave sum, then across waves in fixed order
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
 #pragma unroll
-  for (int k = 0; k < KP; ++k) {
+  for (int k = 0; k < W_KG; ++k) {
     const float v = sum_rows4(sum_row16(fabsf(wn[k])));
     if (lane == 0) colred[wv][k] = v;
   }
   __syncthreads();
-  float nrm[KP];
+  float nrm[W_KG];
 #pragma unroll
-  for (int k = 0; k < KP; ++k) {
+  for (int k = 0; k < W_KG; ++k) {
     float s = 0.f;
     for (int ww = 0; ww < nwv; ++ww) s += colred[ww][k];
     nrm[k] = s;
   }
   if (f < Fs) {
 #pragma unroll
-    for (int k = 0; k < KP; ++k)
-      W[((size_t)u * Fs + f) * KP + k] = (k < K && f < F) ? wn[k] / nrm[k] : 0.f;              // mcem.py:131
+    for (int k = 0; k < W_KG; ++k)
+      W[((size_t)u * Fs + f) * KP + k0 + k] = (k0 + k < K && f < F) ? wn[k] / nrm[k] : 0.f;              // mcem.py:131
   }
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < KP; ++k) normW[(size_t)u * KP + k] = (k < K) ? nrm[k] : 0.f;         // applied to H (mcem.py:133)
+    for (int k = 0; k < W_KG; ++k) normW[(size_t)u * KP + k0 + k] = (k0 + k < K) ? nrm[k] : 0.f;         // applied to H (mcem.py:133)
   }
 }
 
@@ -386,9 +391,9 @@ int vn_launch_w_update(const vaenmf_plan* p, float* W, const float* Ht, hipStrea
   const int threads = ((p->Fs + 63) / 64) * 64;        // one thread per bin (Fs <= 640)
 #define VN_WU(KP)                                                                                               \
   do {                                                                                                          \
-    hipLaunchKernelGGL((w_partial_kernel<KP>), dim3(W_NCH, p->n_utt), dim3(threads), 0, st, p->A1, p->P, Ht,     \
+    hipLaunchKernelGGL((w_partial_kernel<KP>), dim3(W_NCH, p->n_utt), dim3(threads), 0, st, p->A1, p->P, Ht, \
                        p->wpart, p->d_frame_off, p->Fs);                                                        \
-    hipLaunchKernelGGL((w_update_kernel<KP>), dim3(p->n_utt), dim3(threads), 0, st, p->wpart, W, p->normW,       \
+    hipLaunchKernelGGL((w_update_kernel<KP>), dim3(p->n_utt, KP / W_KG), dim3(threads), 0, st, p->wpart, W, p->normW, \
                        p->cfg.F, p->Fs, p->cfg.K);                                                               \
   } while (0)
   switch (p->Kp) { case 8: VN_WU(8); break; case 16: VN_WU(16); break; default: VN_WU(32); break; }

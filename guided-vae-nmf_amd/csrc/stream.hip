@@ -55,6 +55,9 @@
 #ifndef VN_ROWGRP
 #define VN_ROWGRP 6     // rows whose arithmetic the scheduler may interleave in the exact-count stream kernels
 #endif
+#ifndef VN_HG_EXACT2
+#define VN_HG_EXACT2 1     // exact-count H/g kernel for two-chunk rows at rank <= 16 (F = 513, K = 10: 0.2625 -> 0.250 ms)
+#endif
 #ifndef VN_STREAM2
 #define VN_STREAM2 1      // frame-pipelined W-statistics kernel (dev builds: 0 = the batch-at-a-time form)
 #endif
@@ -1288,6 +1291,14 @@ int launch_st(StreamArgs a, int grid, hipStream_t st) {
     } else if (VN_HG_EXACT && NCH == 1 && KP <= 8 && a.R == 10) {
       if (int e = vn_ensure_dyn_lds((const void*)hg_stream_kernel<NCH, KP, ST, (RBm >= 10 && NCH == 1 ? 10 : 0)>, 80 * 1024)) return e;
       hipLaunchKernelGGL((hg_stream_kernel<NCH, KP, ST, (RBm >= 10 && NCH == 1 ? 10 : 0)>), dim3(grid), dim3(256), lds, st, a);
+#if VN_HG_EXACT2
+    } else if (NCH == 2 && sizeof(ST) == 2 && KP == 16 && a.R == 30) {
+      // two 256-bin chunks (F = 513), rank <= 16, bf16 rows: the whole 30-sample frame sits in one batch of registers
+      // (RBX = 32): the exact-count form drops the per-row branches here as well
+      constexpr int RT2 = (NCH == 2 && sizeof(ST) == 2 && KP == 16) ? 30 : 0;
+      if (int e = vn_ensure_dyn_lds((const void*)hg_stream_kernel<NCH, KP, ST, RT2>, 80 * 1024)) return e;
+      hipLaunchKernelGGL((hg_stream_kernel<NCH, KP, ST, RT2>), dim3(grid), dim3(256), lds, st, a);
+#endif
     } else hipLaunchKernelGGL((hg_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
   }
   else hipLaunchKernelGGL((wf_stream_kernel<NCH, KP, ST>), dim3(grid), dim3(256), lds, st, a);
