@@ -1359,6 +1359,10 @@ int launch_w_fused(const vaenmf_plan* p, StreamArgs a, hipStream_t st) {
   a.t64_n0 = p->d_t64_n0; a.t64_cnt = p->d_t64_cnt; a.n_t64 = p->n_t64; a.wpart64 = p->wpart64;
   const size_t lds = ((size_t)a.Fs * 8 + (size_t)4 * wf_acc_floats<8>()) * sizeof(float);
   int grid = a.n_sms * 2;                               // one resident set: 2 workgroups of 4 wavefronts per CU
+  if (const char* e = getenv("VAENMF_WFUSED_GRID")) {   // (tests: a small grid makes every workgroup walk several tiles / utterances)
+    const int g = atoi(e);
+    if (g > 0 && g < grid) grid = g;
+  }
   if (grid > p->n_t64) grid = p->n_t64;
   if (a.R == 30) {
     if (int e = vn_ensure_dyn_lds((const void*)wstats_fused_kernel<8, 30>, 80 * 1024)) return e;

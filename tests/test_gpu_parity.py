@@ -1165,6 +1165,15 @@ def test_fused_w_statistics_equal_the_two_kernel_path(R, counts):
         assert np.max(np.abs(x - y) / (np.abs(y) + 1e-20)) < 2e-5, name
     for x, y in zip(a, a2):
         assert np.array_equal(x, y)
+    # a grid smaller than the tile count (long batches on the real grid): every workgroup walks several tiles and
+    # utterances in its grid-stride loop -- the same sums, bit for bit (a tile's partial does not depend on who computes it)
+    os.environ["VAENMF_WFUSED_GRID"] = "2"
+    try:
+        a3 = run(True)
+    finally:
+        os.environ.pop("VAENMF_WFUSED_GRID", None)
+    for x, y in zip(a, a3):
+        assert np.array_equal(x, y)
     assert float(np.abs(a[0][:, F:]).max()) == 0.0 and float(np.abs(a[0][:, :, K:]).max()) == 0.0 if a[0].shape[2] > K else True
 
 
