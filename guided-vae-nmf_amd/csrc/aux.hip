@@ -223,6 +223,37 @@ __global__ void power_spec_kernel(const float2* __restrict__ X, float* __restric
   if (i < n) { const float2 v = X[i]; X2[i] = v.x * v.x + v.y * v.y; }
 }
 
+// EM.init_parameters on the device (mcem.py:42-44, :51): W = max(U(0,1), eps) over (F, K), H = max(U(0,1), eps) over
+// (K, N), g = 1, padding rows / ranks zero.  Counter-based: the draw of element (utterance, f, k) / (frame inside the
+// utterance, k) is splitmix64(utterance seed ^ salt ^ tag ^ index), so an utterance's initialisation does not depend on the
+// batch it sits in.  One thread per element of W [U][Fs][Kp] followed by Ht [NT][Kp] and g [NT].
+__global__ void nmf_init_kernel(float* __restrict__ W, float* __restrict__ Ht, float* __restrict__ g,
+                                const uint64_t* __restrict__ utt_seed, const int32_t* __restrict__ frame_utt,
+                                const int32_t* __restrict__ frame_loc, int n_utt, int NT, int F, int Fs, int K, int Kp,
+                                uint64_t salt, float eps) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nW = (size_t)n_utt * Fs * Kp, nH = (size_t)NT * Kp;
+  auto u01 = [](uint64_t key) {
+    uint64_t x = key;
+    const uint64_t r = splitmix64(x);
+    return (float)(r >> 40) * 5.9604644775390625e-8f;      // 24 bits, [0, 1)
+  };
+  if (i < nW) {
+    const int k = (int)(i % Kp), f = (int)((i / Kp) % Fs), u = (int)(i / ((size_t)Kp * Fs));
+    float v = 0.f;
+    if (f < F && k < K) v = fmaxf(u01(utt_seed[u] ^ salt ^ (0x57ull << 56) ^ (uint64_t)(f * K + k)), eps);
+    W[i] = v;
+  } else if (i < nW + nH) {
+    const size_t j = i - nW;
+    const int k = (int)(j % Kp), n = (int)(j / Kp);
+    float v = 0.f;
+    if (k < K) v = fmaxf(u01(utt_seed[frame_utt[n]] ^ salt ^ (0x48ull << 56) ^ ((uint64_t)frame_loc[n] * (uint64_t)K + (uint64_t)k)), eps);
+    Ht[j] = v;
+  } else if (i < nW + nH + (size_t)NT) {
+    g[i - nW - nH] = 1.f;
+  }
+}
+
 // ----------------------------------------------------------------------------
 // STFT / iSTFT (python/processing/stft.py -> librosa): radix-2 FFT in LDS, fp64.
 // ----------------------------------------------------------------------------
@@ -433,6 +464,15 @@ extern "C" int vaenmf_power_spec(const float* X, float* X2, int64_t n, void* str
   VN_REQUIRE(X && X2 && n > 0, "vaenmf_power_spec: bad arguments");
   hipLaunchKernelGGL(power_spec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float2*>(X), X2, n);
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int vaenmf_init_nmf(vaenmf_plan* p, float* W, float* Ht, float* g, uint64_t salt, float eps, void* stream) {
+  VN_REQUIRE(p && W && Ht && g && p->NT > 0, "vaenmf_init_nmf: null argument or no batch bound");
+  const size_t n = (size_t)p->n_utt * p->Fs * p->Kp + (size_t)p->NT * p->Kp + (size_t)p->NT;
+  hipLaunchKernelGGL(nmf_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, Ht, g, p->d_utt_seed,
+                     p->d_frame_utt, p->d_frame_loc, p->n_utt, p->NT, p->cfg.F, p->Fs, p->cfg.K, p->Kp, salt, eps);
   VN_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -216,8 +216,11 @@ struct FrameCtx {
           const float* wrow = w_row<L>(utt, f0[c] + t);
 #pragma unroll
           for (int k = 0; k < KP; k += 4) {
+            // (one fused multiply-add per rank, in rank order: the order and rounding of the LDS form above, so that a frame's
+            // result does not depend on whether its utterance's W happens to be the copy staged in LDS -- i.e. on the batch)
             const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow + k);
-            v += w4[0] * h[k] + w4[1] * h[k + 1] + w4[2] * h[k + 2] + w4[3] * h[k + 3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v = __builtin_fmaf(w4[j], h[k + j], v);
           }
           vb[c][t] = v;
         }

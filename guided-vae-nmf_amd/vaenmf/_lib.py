@@ -33,6 +33,7 @@ SIGNATURES = {
     "vaenmf_bind_batch": (_I, [_P, _I, _P, _P]),
     "vaenmf_bind_batch_async": (_I, [_P, _I, _P, _P, _P]),
     "vaenmf_set_noise_psd": (_I, [_P, _P]),
+    "vaenmf_init_nmf": (_I, [_P, _P, _P, _P, C.c_uint64, _F, _P]),
     "vaenmf_layer1_bias": (_I, [_P, _P, _I, _P, _P]),
     "vaenmf_mh_chain": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _F, C.POINTER(Rng), _P, _P]),
     "vaenmf_sample_store": (_I, [_P, _I]),

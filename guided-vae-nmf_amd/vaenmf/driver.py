@@ -83,7 +83,7 @@ def evaluate(rec: Reconstructor, file_paths, processed_data_dir, output_data_dir
             y = (y_soft > 0.5).float()
         elif m2 and classifier is None:
             raise ValueError("label_source='dnn' needs a classifier")
-        s_hat, n_hat, _ = rec.enhance(wav, counts, seeds=seeds, init_seed=seed + b0, y=y,
+        s_hat, n_hat, _ = rec.enhance(wav, counts, seeds=seeds, init_seed=seed, y=y,
                                       classifier=classifier if (m2 and label_source == "dnn") else None, mean=mean, std=std)
         if m2 and label_source == "dnn":
             y_soft, y = rec.y_soft, rec.y_hard

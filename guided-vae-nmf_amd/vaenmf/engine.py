@@ -190,6 +190,12 @@ class BatchEngine:
         self.Ht.copy_(torch.from_numpy(Ht))
         self.g.fill_(1.0)
 
+    def init_nmf_device(self, salt=0, eps=1e-8):
+        """W = max(U(0,1), eps), H = max(U(0,1), eps), g = 1 (mcem.py:42-44, :51) by the library's counter-based generator,
+        keyed by the utterance seeds of bind(): no torch kernel on the throughput path, and an utterance's start does not
+        depend on its batch."""
+        check(lib().vaenmf_init_nmf(self._plan, _ptr(self.W), _ptr(self.Ht), _ptr(self.g), C.c_uint64(int(salt) & (2 ** 64 - 1)), float(eps), _stream()))
+
     def dense(self, x, w, b, act):
         """act(x w^T + b) on the device (models.py:101-104 / 57-62)."""
         M, inn = x.shape

@@ -45,14 +45,9 @@ class Reconstructor:
         X, fc = vstft.stft_batch(wav, sample_counts, self.fs, self.wlen_sec, self.hop_percent, Fs=eng.Fs, device=self.device)
         eng.bind(fc, Rcap=max(self.nsE, self.nsW), seeds=seeds)
         eng.set_spectrogram(X)
-        # W = max(rand(F,K), eps), H = max(rand(K,N), eps), g = 1 (mcem.py:42-44), device generator
-        gen = torch.Generator(device=self.device)
-        gen.manual_seed(int(init_seed))
-        eng.W.zero_()
-        eng.W[:, :self.F, :self.K] = torch.rand(eng.U, self.F, self.K, device=self.device, generator=gen).clamp_min(self.eps)
-        eng.Ht.zero_()
-        eng.Ht[:, :self.K] = torch.rand(eng.NT, self.K, device=self.device, generator=gen).clamp_min(self.eps)
-        eng.g.fill_(1.0)
+        # W = max(rand(F,K), eps), H = max(rand(K,N), eps), g = 1 (mcem.py:42-44, :51): the library's generator, keyed by
+        # the utterance seeds (an utterance's start does not depend on the batch it sits in)
+        eng.init_nmf_device(salt=init_seed, eps=self.eps)
         if classifier is not None:
             self.y_soft, y = eng.classify(classifier, mean, std, self.eps)
             self.y_hard = y

@@ -108,6 +108,12 @@ int vaenmf_bind_batch(vaenmf_plan* p, int32_t n_utt, const int32_t* frame_offset
 int vaenmf_bind_batch_async(vaenmf_plan* p, int32_t n_utt, const int32_t* frame_offsets,
                             const uint64_t* utt_seeds, void* stream);
 
+/* EM.init_parameters (mcem.py:42-44, :51) for the bound batch on the device: W = max(U(0,1), eps) (F x K per utterance),
+ * H = max(U(0,1), eps) (K x N), g = 1; padding zero.  Counter-based draws keyed by (utterance seed of vaenmf_bind_batch,
+ * salt, element): an utterance's initialisation does not depend on the batch it sits in.  W DEV [U][Fs][Kp], Ht DEV
+ * [NT][Kp], g DEV [NT].  (The drop-in classes draw W0 / H0 on the host in the reference's order instead.) */
+int vaenmf_init_nmf(vaenmf_plan* p, float* W, float* Ht, float* g, uint64_t salt, float eps, void* stream);
+
 /* B1[n][h] = b1[h] + sum_d W1[h][L+d] * y[n][d]   (label half of mcem.py:242/261/283).
  * y DEV [NT][Dy]. */
 int vaenmf_layer1_bias(vaenmf_plan* p, const float* y, int32_t Dy, float* B1, void* stream);
