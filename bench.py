@@ -481,7 +481,7 @@ def main():
                 allocs.append(int(lib.vaenmf_plan_query(m1._eng._plan, _lib.Q_DEV_ALLOCS)))
             t1u = sorted(ts[1:])[1]
             cfg1_gpu = {"workload": "BASELINE config 1: one 4 s utterance (%d frames, F=%d, K=%d), %d EM iterations + Wiener chain through "
-                                    "MCEM_M1.init_parameters + run (rng='device', %s, batch of one: the decoding M-step)" % (X1.shape[0], F, args.rank_k, args.niter, args.precision),
+                                    "MCEM_M1.init_parameters + run (rng='device', %s, batch of one, sample store on)" % (X1.shape[0], F, args.rank_k, args.niter, args.precision),
                         "value": X1.shape[0] / t1u, "unit": "frames/s", "seconds_per_utterance": t1u,
                         "seconds_all_calls": [round(t, 4) for t in ts], "timing": "median of calls 2-4 (call 1 builds the engine)",
                         "device_allocations_after_each_call": allocs, "final_cost": float(c1[-1])}

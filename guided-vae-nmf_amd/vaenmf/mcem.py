@@ -47,8 +47,12 @@ class _MCEM:
     model = None
 
     def __init__(self, niter, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25, burnin_WF=75, var_RW=0.01,
-                 rng="replay", precision="bf16x3", reference_compat=True):
+                 rng="replay", precision="bf16x3", reference_compat=True, fused_store=True):
         self.niter = niter
+        # rng="device": run() is ONE call of the fused driver; fused_store=True lets the chain keep its samples' variances
+        # in HBM for the streaming M-step (one 4 s utterance: 69 -> ~40 ms); False decodes the samples again like the
+        # step-wise E_step / M_step calls do (bit-equal to them)
+        self.fused_store = fused_store
         self.nsamples_E_step, self.burnin_E_step = nsamples_E_step, burnin_E_step
         self.nsamples_WF, self.burnin_WF = nsamples_WF, burnin_WF
         self.var_RW = var_RW
@@ -192,7 +196,7 @@ class _MCEM:
         if self.rng == "device":
             ns, bi = self.e_step_counts()
             nw, bw = self.wf_counts()
-            c, S, Nn = self._eng.run(self.niter, ns, bi, nw, bw, self.var_RW, store=False)      # (one utterance: the decoding M-step, bit-equal to the step-wise calls)
+            c, S, Nn = self._eng.run(self.niter, ns, bi, nw, bw, self.var_RW, store=bool(self.fused_store))
             cost[:] = c[0].cpu().numpy()
             self._R = nw
         else:
@@ -230,8 +234,9 @@ class EM_noNMF(_MCEM):
     model = "M2"
 
     def __init__(self, X, Vb, g, vae, niter=100, device="cpu", nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25,
-                 burnin_WF=75, var_RW=0.01, rng="replay", precision="bf16x3"):
-        super().__init__(niter, nsamples_E_step, burnin_E_step, nsamples_WF, burnin_WF, var_RW, rng=rng, precision=precision)
+                 burnin_WF=75, var_RW=0.01, rng="replay", precision="bf16x3", fused_store=True):
+        super().__init__(niter, nsamples_E_step, burnin_E_step, nsamples_WF, burnin_WF, var_RW, rng=rng, precision=precision,
+                         fused_store=fused_store)
         dev = torch.device(device if device not in (None, "cpu") else "cuda:0")
         N, F = X.shape
         sd = _state(vae)
@@ -261,11 +266,11 @@ class MCEM_M2_noNMF(EM_noNMF):
     fused driver (vaenmf_em_run serves the fixed-noise model too: the chain reads the given Vb, the M-step is gains-only)."""
 
     def __init__(self, X, Vb, g, Z, y, vae, niter, device, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25,
-                 burnin_WF=75, var_RW=0.01, rng="replay", precision="bf16x3"):
+                 burnin_WF=75, var_RW=0.01, rng="replay", precision="bf16x3", fused_store=True):
         if type(vae).__name__ == "RVAE":
             raise NameError("MCEM algorithm only valid for FFNN VAE")          # mcem.py:614-615
         super().__init__(X, Vb, g, vae, niter, device, nsamples_E_step, burnin_E_step, nsamples_WF, burnin_WF, var_RW,
-                         rng=rng, precision=precision)
+                         rng=rng, precision=precision, fused_store=fused_store)
         eng, N = self._eng, self._N
         eng.Z.zero_()
         eng.Z[:, :self._L].copy_(torch.as_tensor(Z, dtype=torch.float32).reshape(N, self._L))   # mcem.py:617

@@ -727,7 +727,7 @@ def test_nonmf_fused_run_equals_stepwise():
     for fused in (True, False):
         m = vaenmf.MCEM_M2_noNMF(X=z["X"], Vb=z["Vb"], g=torch.tensor(z["g0"]), Z=torch.tensor(z["Z0"]), y=torch.tensor(z["y"]),
                                  vae=vae, niter=3, device="cuda:0", nsamples_E_step=nsE, burnin_E_step=biE,
-                                 nsamples_WF=nsW, burnin_WF=biW, var_RW=0.01, rng="device")
+                                 nsamples_WF=nsW, burnin_WF=biW, var_RW=0.01, rng="device", fused_store=False)
         if fused:
             cost = m.run()
         else:
