@@ -17,7 +17,7 @@ for p in "abc":
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); nd = collections.defaultdict(set); dur = collections.defaultdict(float)
     for r in csv.DictReader(open(fs[0])):
         k = short(r["Kernel_Name"])
-        if not any(s in k for s in ("mh_chain", "wchain", "decode_kernel", "stream_kernel", "w_update", "w_partial")): continue
+        if not any(s in k for s in ("mh_chain", "wchain", "decode_kernel", "stream_kernel", "fused_kernel", "rot_kernel", "w_update", "w_partial")): continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); nd[k].add(r["Dispatch_Id"])
         dur[(k, r["Dispatch_Id"])] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     for k in agg:

@@ -16,7 +16,7 @@ for p in "ab":
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); nd = collections.defaultdict(set)
     for r in csv.DictReader(open(fs[0])):
         k = short(r["Kernel_Name"])
-        if not any(s in k for s in ("stream", "wchain")): continue
+        if not any(s in k for s in ("stream", "wchain", "fused", "rot_kernel")): continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); nd[k].add(r["Dispatch_Id"])
     for k in agg:
         print(k, "launches", len(nd[k]))
