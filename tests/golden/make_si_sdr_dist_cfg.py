@@ -6,14 +6,14 @@ VariationalAutoencoder, python.metrics.energy_ratios -- build container only, it
 EM over 8 short synthetic utterances x S seeds of torch's global generator, with the oracle's STFT / iSTFT around it (the
 reference's own front end needs librosa).  Committed output: data only.  One process per (utterance, seed) task, one
 torch thread each (the tensors are tiny), so that the fixtures of round 3 -- about 6 000 reference runs -- fit a few
-hours of this container's 8 cores:
+hours of this container's 8 cores (a fixture that exists is extended, not recomputed: only its missing seeds run):
 
   si_sdr_dist_n100.npz       F=257, K=8,  niter=100   BASELINE config 2 at its own iteration count      8 x 96 seeds
   si_sdr_dist_f513k10.npz    F=513, K=10, niter=100   the reference scripts' own shape (evaluate_M1.py:77-92) 8 x 64
   si_sdr_dist_f513k32.npz    F=513, K=32, niter=100   the stress rank of BASELINE config 5               8 x 48
-  si_sdr_dist_ext.npz        F=257, K=8,  niter=20    seeds 192..575 on top of si_sdr_dist.npz (same seeding rule):
-                                                      576 seeds per utterance bring 3 sigma of the combined spread
-                                                      of reference and GPU under 0.01 dB
+  si_sdr_dist_ext.npz        F=257, K=8,  niter=20    seeds 192..639 on top of si_sdr_dist.npz (same seeding rule):
+                                                      640 seeds per utterance bring 3 sigma of the combined spread
+                                                      of reference and GPU under 0.01 dB (0.0094)
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_si_sdr_dist_cfg.py <name>|all [procs]
 """
@@ -29,7 +29,7 @@ CFG = {   # name: (F, K, niter, wlen, first seed, seeds)
     "si_sdr_dist_n100": (257, 8, 100, 32e-3, 0, 96),
     "si_sdr_dist_f513k10": (513, 10, 100, 64e-3, 0, 64),
     "si_sdr_dist_f513k32": (513, 32, 100, 64e-3, 0, 48),
-    "si_sdr_dist_ext": (257, 8, 20, 32e-3, 192, 384),
+    "si_sdr_dist_ext": (257, 8, 20, 32e-3, 192, 448),
 }
 UTTS, FS, T = 8, 16000, 16000
 _state = {}
@@ -84,7 +84,14 @@ def main():
             F, K, niter, wlen, s0, S = CFG[name]
             out = np.zeros((UTTS, S, 4))
             t0 = time.time()
-            todo = [(F, K, niter, wlen, u, s0 + i) for i in range(S) for u in range(UTTS)]
+            have = 0
+            fx = os.path.join(HERE, name + ".npz")
+            if os.path.exists(fx):                      # keep the runs a shorter fixture of the same configuration already holds
+                z = np.load(fx)
+                if (int(z["F"]), int(z["K"]), int(z["niter"]), int(z["first_seed"])) == (F, K, niter, s0) and z["results"].shape[1] <= S:
+                    have = z["results"].shape[1]
+                    out[:, :have] = z["results"]
+            todo = [(F, K, niter, wlen, u, s0 + i) for i in range(have, S) for u in range(UTTS)]
             for k, (u, sd, r) in enumerate(pool.imap_unordered(task, todo, chunksize=4)):
                 out[u, sd - s0] = r
                 if (k + 1) % 64 == 0:
