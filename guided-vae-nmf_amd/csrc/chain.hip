@@ -40,6 +40,10 @@ __device__ long long g_wc_stamp[32];
 #ifndef VN_PACKED
 #define VN_PACKED 1
 #endif
+#ifndef VN_PFL
+#define VN_PFL 3      // bf16x3 mode, F > 80: tiles of W3-lo fragments (streamed from L2, ~1 us away) in flight ahead of their MFMAs -- with one
+                      // tile the single wavefront of a SIMD sat out the L2 latency once per bin tile
+#endif
 #ifndef VN_TPM
 #define VN_TPM 2      // transcendentals scheduled right behind each MFMA (a packed instruction waits for a matrix instruction in flight); 0: mixed with the other VALU work
 #endif
@@ -218,6 +222,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
   __amdgpu_buffer_rsrc_t vbin_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Vb), 0, a.Vb ? (int)((unsigned)a.NT * (unsigned)a.Fs * 4u) : 0, 0x00020000);
   __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, a.W ? (int)((unsigned)a.n_utts * (unsigned)a.Fs * (unsigned)a.Kp * 4u) : 0, 0x00020000);
   __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Ht), 0, a.Ht ? (int)((unsigned)a.NT * (unsigned)a.Kp * 4u) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t z_rs = __builtin_amdgcn_make_buffer_rsrc(a.Z, 0, (int)((unsigned)a.NT * LAT * 4u), 0x00020000);
+  __amdgpu_buffer_rsrc_t b1in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B1), 0, M2 ? (int)((unsigned)a.NT * HID * 4u) : 0, 0x00020000);
   __amdgpu_buffer_rsrc_t u_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u ? (int)((unsigned)a.NT * (unsigned)S * 4u) : 0, 0x00020000);
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
     if (M2) {
 #pragma unroll
       for (int t = 0; t < NTH; ++t) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.B1 + (size_t)nrow * HID + 16 * t + 4 * q);
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b1in_rs, ((unsigned)nrow * HID + 4u * (unsigned)q) * 4u + 64u * (unsigned)t, 0, 0));
         if (B1L) *reinterpret_cast<u32x2*>(b1stash + t * 512) = u32x2{pk2(v[0], v[1]), pk2(v[2], v[3])};
         else b1r[(M2 && !B1L) ? t : 0] = v;
       }
@@ -287,8 +293,11 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
     // ---- current latent state, fragment order: latents 4q..4q+3 and 16+4q..16+4q+3 of frame c
     float z[8];
     {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(a.Z + (size_t)nrow * LAT + 4 * q);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(a.Z + (size_t)nrow * LAT + 16 + 4 * q);
+      // (buffer-addressed like everything else per frame: a 64-bit address pair here was loop-invariant in its lane part,
+      //  hoisted out of the wave-tile loop and spilled -- the kernel's only scratch)
+      const unsigned zo = ((unsigned)nrow * LAT + 4u * (unsigned)q) * 4u;
+      const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rs, zo, 0, 0));
+      const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rs, zo + 64u, 0, 0));
 #pragma unroll
       for (int t = 0; t < 4; ++t) { z[t] = lo[t]; z[4 + t] = hi[t]; }
     }
@@ -309,8 +318,10 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
     Xs128 st0, st1;
     if (a.rng_mode == VAENMF_RNG_DEVICE) {
       const uint32_t floc = (uint32_t)(nrow - a.frame_off[utt]);
-      st0 = xs_seed(a.utt_seed[utt], floc, (uint32_t)q, a.call);
-      st1 = xs_seed(a.utt_seed[utt], floc, (uint32_t)(4 + q), a.call);
+      int qs = q;                                          // (opaque: the key words are built here, once per wave tile, not hoisted and spilled)
+      asm volatile("" : "+v"(qs));
+      st0 = xs_seed(a.utt_seed[utt], floc, (uint32_t)qs, a.call);
+      st1 = xs_seed(a.utt_seed[utt], floc, (uint32_t)(4 + qs), a.call);
     }
 
     // E(z) = sum_f [log Vx + X2 / Vx] of this lane's frame (all lanes of the frame get the sum).  fp64 across
@@ -339,24 +350,36 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
       // MFMAs of tile t issued and the epilogue of tile t-1 computed in the same scheduling region, so a
       // wavefront covers its own LDS and MFMA latencies with epilogue work.
       //   NKS k-steps; frag(t, s, hi, lo) loads; bias(t); bop(s, hi, lo) the input fragments; epi(t, acc)
-      auto run_layer = [&](auto nks_c, auto ntiles_c, auto frag, auto bias, auto bop, auto epi) {
+      //   frag_lo(t, s, lo): the lo fragments (bf16x3 mode), PFL tiles ahead
+      auto run_layer = [&](auto nks_c, auto ntiles_c, auto pfl_c, auto frag, auto frag_lo, auto bias, auto bop, auto epi) {
         constexpr int NKS = decltype(nks_c)::value, N = decltype(ntiles_c)::value;
         // VN_PF tiles of weight fragments (and bias) in flight ahead of the MFMAs that use them
         constexpr int PF = VN_PF, NB = PF + 1;
-        bf16x8 wh[NB][NKS], wl[NB][NKS];
+        constexpr int PFL = SPLIT ? decltype(pfl_c)::value : 0, NBL = PFL + 1;
+        bf16x8 wh[NB][NKS], wl[NBL][NKS];
         f32x4 acc[2], bq[NB];
+#pragma unroll
+        for (int p = 0; p < PFL; ++p)
+          if (p < N) {
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) frag_lo(p, s, wl[p % NBL][s]);
+          }
 #pragma unroll
         for (int p = 0; p < PF; ++p)
           if (p < N) {
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) frag(p, s, wh[p % NB][s], wl[p % NB][s]);
+            for (int s = 0; s < NKS; ++s) frag(p, s, wh[p % NB][s]);
             bq[p % NB] = bias(p);
           }
 #pragma unroll
         for (int t = 0; t <= N; ++t) {
+          if (SPLIT && t + PFL < N && tile_on3(N, t + PFL)) {
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) frag_lo(t + PFL, s, wl[(t + PFL) % NBL][s]);
+          }
           if (t + PF < N && tile_on3(N, t + PF)) {
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) frag(t + PF, s, wh[(t + PF) % NB][s], wl[(t + PF) % NB][s]);
+            for (int s = 0; s < NKS; ++s) frag(t + PF, s, wh[(t + PF) % NB][s]);
             bq[(t + PF) % NB] = bias(t + PF);
           }
           if (t < N && tile_on3(N, t)) {
@@ -365,7 +388,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
             for (int s = 0; s < NKS; ++s) {
               bf16x8 ah, al;
               bop(s, ah, al);
-              ac = mma<SPLIT>(wh[t % NB][s], wl[t % NB][s], ah, al, ac);
+              ac = mma<SPLIT>(wh[t % NB][s], SPLIT ? wl[t % NBL][s] : wh[t % NB][s], ah, al, ac);
             }
             acc[t & 1] = ac;
           }
@@ -405,12 +428,9 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
           bl[0][2] = pk2(zz[4] - bf_lo(bh[0][2]), zz[5] - bf_hi(bh[0][2]));
           bl[0][3] = pk2(zz[6] - bf_lo(bh[0][3]), zz[7] - bf_hi(bh[0][3]));
         }
-        run_layer(std::integral_constant<int, 1>{}, std::integral_constant<int, NTH>{},
-                  [&](int t, int, bf16x8& hi, bf16x8& lo) {
-                    const char* p = smem + L::W1 + t * PARTS * 1024 + l16;
-                    hi = *reinterpret_cast<const bf16x8*>(p);
-                    lo = SPLIT ? *reinterpret_cast<const bf16x8*>(p + 1024) : hi;
-                  },
+        run_layer(std::integral_constant<int, 1>{}, std::integral_constant<int, NTH>{}, std::integral_constant<int, VN_PF>{},
+                  [&](int t, int, bf16x8& hi) { hi = *reinterpret_cast<const bf16x8*>(smem + L::W1 + t * PARTS * 1024 + l16); },
+                  [&](int t, int, bf16x8& lo) { lo = *reinterpret_cast<const bf16x8*>(smem + L::W1 + t * PARTS * 1024 + (SPLIT ? 1024 : 0) + l16); },
                   [&](int t) {
                     if (B1L) {
                       const u32x2 w = *reinterpret_cast<const u32x2*>(b1stash + t * 512);
@@ -427,12 +447,9 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
 #pragma unroll
         for (int s = 0; s < NK; ++s) { bh[s] = ch[s]; if (SPLIT) bl[s] = cl[s]; }
       } else
-      run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, NTH>{},
-                [&](int t, int s, bf16x8& hi, bf16x8& lo) {
-                  const char* p = smem + L::W2 + (t * NK + s) * PARTS * 1024 + l16;
-                  hi = *reinterpret_cast<const bf16x8*>(p);
-                  lo = SPLIT ? *reinterpret_cast<const bf16x8*>(p + 1024) : hi;
-                },
+      run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, NTH>{}, std::integral_constant<int, VN_PF>{},
+                [&](int t, int s, bf16x8& hi) { hi = *reinterpret_cast<const bf16x8*>(smem + L::W2 + (t * NK + s) * PARTS * 1024 + l16); },
+                [&](int t, int s, bf16x8& lo) { lo = *reinterpret_cast<const bf16x8*>(smem + L::W2 + (t * NK + s) * PARTS * 1024 + (SPLIT ? 1024 : 0) + l16); },
                 [&](int t) { return *reinterpret_cast<const f32x4*>(b2l + 16 * t + 4 * q); },
                 [&](int s, bf16x8& hi, bf16x8& lo) { hi = __builtin_bit_cast(bf16x8, ch[s]); lo = SPLIT ? __builtin_bit_cast(bf16x8, cl[s]) : hi; },
                 [&](int t, const f32x4 acc) { put(bh, bl, t, tanh4(acc)); });
@@ -443,13 +460,14 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
       f32x2 pl2 = {0.f, 0.f}, px2 = {0.f, 0.f};
       (void)ef;
       unsigned pk_even0 = 0, pk_even1 = 0;
-      run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, MAXT>{},
-                [&](int t, int s, bf16x8& hi, bf16x8& lo) {
+      run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, MAXT>{}, std::integral_constant<int, (SPLIT && !LOL) ? VN_PFL : VN_PF>{},
+                [&](int t, int s, bf16x8& hi) {
                   if (GT > 0 && t < GT) hi = gfr[t < GT ? t : 0][s];
                   else if (HIALL || t - GT < n_hi) hi = *reinterpret_cast<const bf16x8*>(smem + L::W3 + ((t - GT) * NK + s) * 1024 + l16);
                   else hi = *reinterpret_cast<const bf16x8*>(w3g + (size_t)((t * NK + s) * 2) * 1024 + l16);
-                  if (!SPLIT) lo = hi;
-                  else if (LOL) lo = *reinterpret_cast<const bf16x8*>(w3lo_lds + (t * NK + s) * 1024 + l16);
+                },
+                [&](int t, int s, bf16x8& lo) {
+                  if (LOL) lo = *reinterpret_cast<const bf16x8*>(w3lo_lds + (t * NK + s) * 1024 + l16);
                   else lo = *reinterpret_cast<const bf16x8*>(w3g + (size_t)((t * NK + s) * 2 + 1) * 1024 + l16);
                 },
                 [&](int t) { return *reinterpret_cast<const f32x4*>(b3l + 16 * t + 4 * q); },
@@ -600,10 +618,10 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
       WC_STAMP(4);
     }
     WC_STAMP_FLUSH;
-    if (a.update_Z && fvalid) {                         // self.Z = last draw (mcem.py:466)
-      float* dst = a.Z + (size_t)nrow * LAT;
-      *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{z[0], z[1], z[2], z[3]};
-      *reinterpret_cast<f32x4*>(dst + 16 + 4 * q) = f32x4{z[4], z[5], z[6], z[7]};
+    if (a.update_Z) {                                   // self.Z = last draw (mcem.py:466); idle lanes: offset behind the buffer
+      const unsigned zo = fvalid ? rp_off : WC_OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{z[0], z[1], z[2], z[3]}), z_rs, zo, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{z[4], z[5], z[6], z[7]}), z_rs, zo + 64u, 0, 0);
     }
   }
 }
@@ -667,6 +685,7 @@ extern "C" int vaenmf_wchain_addressable(int64_t NT, int32_t Rcap, int32_t steps
   const uint64_t nt = (uint64_t)(NT > 0 ? NT : 0), S = (uint64_t)(steps > 0 ? steps : 0);
   if (nt * (uint64_t)Rcap * LAT * 4 >= lim) return 0;                  // Zs
   if (nt * (uint64_t)Fs * 4 >= lim) return 0;                          // X2, Vb
+  if (nt * (uint64_t)HID * 4 >= lim) return 0;                         // B1 (M2), Z
   if ((uint64_t)n_utt * (uint64_t)Fs * (uint64_t)Kp * 4 >= lim) return 0;   // W
   if (nt * (uint64_t)Kp * 4 >= lim) return 0;                          // Ht
   if (nt * S * 4 >= lim) return 0;                                     // acc_out, u
