@@ -12,8 +12,14 @@ from ._lib import check, lib
 LAT, HID = 32, 128
 
 
-def _ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+def _ptr(t, rows_strided=False):
+    """Raw address of a tensor handed to the C ABI (row-major, dense: the library knows no strides; `rows_strided`: a row
+    stride goes along, as for vaenmf_dense's input).  A transposed / sliced view would be read as something else entirely."""
+    if t is None:
+        return None
+    if not (t.is_contiguous() or (rows_strided and t.dim() == 2 and t.stride(1) == 1)):
+        raise ValueError("the C ABI takes dense row-major buffers; got strides %s for shape %s (call .contiguous())" % (tuple(t.stride()), tuple(t.shape)))
+    return C.c_void_p(t.data_ptr())
 
 
 def _stream():
@@ -201,7 +207,7 @@ class BatchEngine:
         M, inn = x.shape
         out = w.shape[0]
         y = torch.empty(M, out, device=self.device, dtype=torch.float32)
-        check(lib().vaenmf_dense(_ptr(x), M, inn, x.stride(0), _ptr(w), _ptr(b), out, act, _ptr(y), out, _stream()))
+        check(lib().vaenmf_dense(_ptr(x, rows_strided=True), M, inn, x.stride(0), _ptr(w), _ptr(b), out, act, _ptr(y), out, _stream()))
         return y
 
     def _dev(self, a):

@@ -1331,3 +1331,117 @@ def test_an_utterances_result_does_not_depend_on_its_batch(nfft, K, prec, store)
             assert np.array_equal(x, y), i
     for x, y in zip(a[6], c[6]):
         assert np.array_equal(x, y)
+
+
+class _RecordingRNG:
+    """Seeded numpy generator (the oracle's NumpyRNG) that keeps what it drew, in order."""
+
+    def __init__(self, seed):
+        self.g, self.draws = orc.NumpyRNG(seed), []
+
+    def rand(self, *shape):
+        self.draws.append(self.g.rand(*shape))
+        return self.draws[-1]
+
+    def randn(self, *shape):
+        self.draws.append(self.g.randn(*shape))
+        return self.draws[-1]
+
+
+def _oracle_one_iteration(X, params, K, seed0, min_margin=5e-4):
+    """One EM iteration + the Wiener chain of the oracle on a recorded numpy stream; the stream's seed is advanced until every
+    accept / reject decision of both chains sits at least `min_margin` from its threshold (a replayed trajectory is only
+    comparable while the decisions agree; the reference-generated goldens were selected the same way, at 1e-3; the HIP
+    path's log-acceptances are within 1e-4 of the oracle's on these sizes)."""
+    for k in range(200):
+        o = orc.MCEMOracle("M1", 1, 10, 30, 25, 75, 0.01, reference_compat=True)
+        r = _RecordingRNG(seed0 + 1000 * k)
+        o.init_parameters(X, params, K, 1e-8, r)
+        out = dict(o=o, W0=o.W.copy(), H0=o.H.copy(), Z0=o.Z.copy())
+        ns, bi = o.e_step_counts()
+        nw, bw = o.wf_counts()
+        tr, p0 = [], len(r.draws)
+        Zs = o.sample_posterior(o.Z, ns, bi, trace=tr)
+        out["e_draws"], out["acc"], out["Zs"] = r.draws[p0:], np.stack([t["acc"] for t in tr]), Zs
+        o.Z = Zs[:, -1, :].T.copy()
+        o.compute_Vs(Zs); o.compute_Vs_scaled(); o.compute_Vx()
+        o.M_step()
+        out["W"], out["H"], out["g"], out["cost"] = o.W.copy(), o.H.copy(), o.g.copy(), float(o.compute_expected_neg_log_like())
+        tr2, p1 = [], len(r.draws)
+        Zw = o.sample_posterior(o.Z, nw, bw, trace=tr2)
+        out["w_draws"] = r.draws[p1:]
+        o.compute_Vs(Zw); o.compute_Vs_scaled(); o.compute_Vx()
+        out["WFs"], out["WFn"] = o.compute_WF(sample=False)
+        margins = [np.abs(np.log(d[2 * m + 1]) - t["acc"]).min() for d, trc in ((out["e_draws"], tr), (out["w_draws"], tr2)) for m, t in enumerate(trc)]
+        if min(margins) > min_margin:
+            return out
+    raise AssertionError("no stream with clear decisions found")
+
+
+def _replay_tensors(outs, key, S, dev):
+    # (ascontiguousarray: stacking transposed views keeps THEIR memory order, and the C ABI takes dense row-major buffers)
+    eps = np.ascontiguousarray(np.concatenate([np.stack([o[key][2 * m].T for m in range(S)]) for o in outs], 1))      # [S, NT, L]
+    u = np.ascontiguousarray(np.concatenate([np.stack([o[key][2 * m + 1] for m in range(S)]) for o in outs], 1))      # [S, NT]
+    return torch.from_numpy(eps).to(dev), torch.from_numpy(u).to(dev), u
+
+
+@pytest.mark.parametrize("counts,prec", [([1], "bf16x3"), ([3], "bf16x3"), ([17], "bf16x3"), ([1, 2, 19, 16, 1], "bf16x3"), ([1, 2, 19, 16, 1], "bf16")])
+def test_tiny_and_ragged_utterances_against_the_oracle(counts, prec):
+    """Edge sizes: utterances of ONE frame, of fewer frames than a wavefront's 16, of 16 k + 1 and 16 k + 3 frames, alone and
+    in one ragged batch -- one EM iteration (chain with every log-acceptance and decision, samples, M-step, cost) and the
+    Wiener filter against the oracle run per utterance on the same draws (mcem.py:371-441, :90-152, :473-490).  bf16x3:
+    the golden-run tolerances; bf16 (wave chain + sample store): finite, the same decisions where the margin is wide."""
+    need_gpu()
+    F, K, L = 65, 4, 32
+    params = orc.xavier_normal_params([F, L, [128, 128]], seed=3, bias_std=0.05)
+    gx = np.random.RandomState(11)
+    Xs = [((gx.randn(n, F) + 1j * gx.randn(n, F)) * np.exp(0.5 * gx.randn(n, 1))).astype(np.complex64) for n in counts]
+    outs = [_oracle_one_iteration(X, params, K, 100 + i) for i, X in enumerate(Xs)]
+    ns, bi = outs[0]["o"].e_step_counts()
+    nw, bw = outs[0]["o"].wf_counts()
+    NT = sum(counts)
+    eng = make_engine(params, F, K, counts, Rcap=max(ns, nw), precision=prec)
+    dev = eng.device
+    eng.set_spectrogram(Xs)
+    eng.init_nmf([o["W0"] for o in outs], [o["H0"] for o in outs])
+    eng.Z.zero_()
+    eng.Z[:, :L].copy_(torch.from_numpy(np.ascontiguousarray(np.concatenate([o["Z0"].T for o in outs], 0))))
+    S = ns + bi
+    eps, u_d, u = _replay_tensors(outs, "e_draws", S, dev)
+    acc_ref = np.concatenate([o["acc"] for o in outs], 1)
+    acc = eng.mh_chain(ns, bi, 0.01, eps=eps, u=u_d, want_acc=True).cpu().numpy()
+    assert acc.shape == (S, NT) and np.all(np.isfinite(acc))
+    if prec != "bf16x3":
+        # bf16 products: the trajectories part ways at the first narrow decision; until then the decisions agree
+        wide = np.abs(np.log(u) - acc_ref) > 0.5
+        first = np.argmax(~np.equal(np.log(u) < acc, np.log(u) < acc_ref), axis=0)        # per frame: first step that differs (0 if none)
+        for n in range(NT):
+            m = first[n] if (np.log(u[:, n]) < acc[:, n])[first[n]] != (np.log(u[:, n]) < acc_ref[:, n])[first[n]] else S
+            assert m == S or not wide[m, n], (n, m)
+        eng.m_step(ns)
+        for t in (eng.W, eng.Ht, eng.g):
+            assert bool(torch.isfinite(t).all())
+        assert np.all(np.isfinite(eng.cost_from_frames(ns)))
+        return
+    assert np.max(np.abs(acc - acc_ref)) < 2e-3
+    assert np.array_equal(np.log(u) < acc, np.log(u) < acc_ref)
+    Zs_ref = np.concatenate([o["Zs"] for o in outs], 0)
+    assert np.max(np.abs(eng.Zs[:, :ns, :L].cpu().numpy() - Zs_ref)) < 5e-6
+    eng.m_step(ns)
+    cost = eng.cost_from_frames(ns)
+    off = np.concatenate([[0], np.cumsum(counts)])
+    for i, o in enumerate(outs):
+        sl = slice(off[i], off[i + 1])
+        assert rel_err(eng.W[i, :F, :K].cpu().numpy(), o["W"]) < 5e-4
+        assert rel_err(eng.Ht[sl, :K].cpu().numpy().T, o["H"]) < 5e-4
+        assert rel_err(eng.g[sl].cpu().numpy(), o["g"]) < 5e-4
+        assert abs(cost[i] - o["cost"]) / abs(o["cost"]) < 1e-4
+    # Wiener filter with the samples of a second chain
+    eps, u_d, _ = _replay_tensors(outs, "w_draws", nw + bw, dev)
+    eng.mh_chain(nw, bw, 0.01, eps=eps, u=u_d, update_Z=False)
+    Sh, Nh, WFs, WFn = eng.wiener(nw, want_masks=True)
+    for i, o in enumerate(outs):
+        sl = slice(off[i], off[i + 1])
+        assert rel_err(WFs[sl, :F].cpu().numpy().T, o["WFs"]) < 5e-3
+        sh = np.ascontiguousarray(Sh[sl, :F].cpu().numpy()).view(np.complex64).reshape(counts[i], F).T
+        assert nrm_err(sh, o["WFs"] * o["o"].X) < 2e-3

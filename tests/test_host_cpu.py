@@ -264,3 +264,19 @@ def test_committed_traffic_profiles_name_every_kernel_the_bench_reports():
             hit = [v for k, v in kern.items() if sub in k]
             assert hit and hit[0]["hbm_bytes_per_launch"] > 0 and hit[0]["launches"] > 0, (tag, sub)
         assert os.path.exists(os.path.join(prof, "round3_%s_summary.txt" % tag))
+
+
+def test_c_abi_pointers_reject_strided_views():
+    """The library knows no strides: a transposed or column-sliced tensor handed to the ctypes layer must fail loudly
+    instead of being read as a dense row-major buffer (a replay-noise tensor built from transposed views once was)."""
+    import torch
+    from vaenmf.engine import _ptr
+    t = torch.zeros(6, 4)
+    assert _ptr(None) is None and _ptr(t) is not None and _ptr(t[:3]) is not None
+    with pytest.raises(ValueError):
+        _ptr(t.t())
+    with pytest.raises(ValueError):
+        _ptr(t[:, :2])
+    assert _ptr(t[:, :2], rows_strided=True) is not None          # vaenmf_dense takes a row stride
+    with pytest.raises(ValueError):
+        _ptr(t.t(), rows_strided=True)
