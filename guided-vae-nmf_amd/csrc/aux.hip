@@ -261,10 +261,10 @@ __device__ __forceinline__ int bitrev(int x, int bits) { return (int)(__brev((un
 
 // in-place complex FFT of length n (power of two) on LDS arrays; sign = -1 forward, +1 inverse
 __device__ void fft_lds(double* re, double* im, const double* twr, const double* twi, int n, int bits, int sign) {
-  for (int len = 2, st = n >> 1; len <= n; len <<= 1, st >>= 1) {
-    const int half = len >> 1;
+  for (int len = 2, st = n >> 1, lh = 0; len <= n; len <<= 1, st >>= 1, ++lh) {
+    const int half = len >> 1;                     // = 1 << lh
     for (int b = threadIdx.x; b < (n >> 1); b += blockDim.x) {
-      const int grp = b / half, pos = b - grp * half;
+      const int grp = b >> lh, pos = b & (half - 1);
       const int i0 = grp * len + pos, i1 = i0 + half;
       const double wr = twr[pos * st], wi = sign * twi[pos * st];
       const double xr = re[i1] * wr - im[i1] * wi, xi = re[i1] * wi + im[i1] * wr;
@@ -293,13 +293,14 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav
     sincospi(-2.0 * t / nfft, &s, &c);           // exp(-2 pi i t / nfft)
     twr[t] = c; twi[t] = s;
   }
+  __syncthreads();
   for (int t = threadIdx.x; t < nfft; t += blockDim.x) {
     int64_t p = (int64_t)i * hop + t - nfft / 2;  // centre=True, reflect padding
     if (p < 0) p = -p;
     if (p >= Tp) p = 2 * (Tp - 1) - p;
     const double v = (p >= 0 && p < T) ? (double)wav[off + p] : 0.0;
-    double sw, cw;
-    sincospi(2.0 * t / nfft, &sw, &cw);
+    // cos(2 pi t / nfft) from the twiddle table (two thirds of this kernel's time went into a second fp64 sincospi per sample)
+    const double cw = t < nfft / 2 ? twr[t] : -twr[t - nfft / 2];
     const int r = bitrev(t, bits);
     re[r] = v * (0.5 - 0.5 * cw);                 // periodic Hann
     im[r] = 0.0;
@@ -336,8 +337,7 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float2* __restr
   __syncthreads();
   fft_lds(re, im, twr, twi, nfft, bits, 1);
   for (int t = threadIdx.x; t < nfft; t += blockDim.x) {
-    double sw, cw;
-    sincospi(2.0 * t / nfft, &sw, &cw);
+    const double cw = t < nfft / 2 ? twr[t] : -twr[t - nfft / 2];     // cos(2 pi t / nfft), see stft_kernel
     work[(size_t)n * nfft + t] = (float)(re[t] / nfft * (0.5 - 0.5 * cw));
   }
 }
