@@ -626,6 +626,328 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small batches (no more wave tiles than CUs: one utterance through the drop-in classes is 32 tiles): FOUR wavefronts,
+// one per SIMD of a CU, share one tile of 16 frames.  bf16 mode, 17 bin tiles (F = 257..272).  Every wavefront draws the
+// noise and takes the accept decision redundantly (same keys, same instructions: same bits).  Of each hidden layer it
+// computes TWO of the eight feature tiles -- in the accumulator = operand layout of this file exactly ONE k-step of the
+// next layer's input fragments, 16 bytes per lane -- and the four k-steps are exchanged through LDS; of the output layer it
+// owns TWO of the eight bin-tile pairs (wavefront 0 also the odd 17th tile): X2 / Vb of 4-5 tiles instead of 17, a quarter
+// of the MFMAs, transcendentals and row stores.  The per-pair fp32 energy sums go through LDS as well and every wavefront
+// adds all nine in the order the one-wavefront kernel adds them, so the acceptance decisions -- and with them every
+// result -- are bit-identical to wchain_kernel's (tested).  Three workgroup barriers per evaluation.  A lone wavefront per
+// SIMD needed 7 450 cycles per evaluation for the whole decoder.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool STORE, bool M2>
+__global__ __launch_bounds__(256, 1) void wchain4_kernel(const WcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = WcLds<false>;
+  constexpr int MAXT = 17, NOWN = 5, NWV = 4;
+  constexpr int XH1 = L::W3 + MAXT * NK * 1024;          // exchange areas: hidden activations u32x4 [4][64] per hidden layer,
+  constexpr int XH2 = XH1 + 4 * 64 * 16;                 // pair energies float [12][64]
+  constexpr int EXB = XH2 + 4 * 64 * 16;
+  {
+    const int nthr = NWV * 64;
+    auto stage = [&](char* dst, const __bf16* srcp, int nblk) {    // hi blocks [blk][2 parts] -> [blk]
+      for (int e = threadIdx.x; e < nblk * 64; e += nthr) {
+        const int chunk = e & 63, b = e >> 6;
+        *reinterpret_cast<f32x4*>(dst + (size_t)e * 16) =
+            *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(srcp) + ((size_t)(b * 2) * 64 + chunk) * 16);
+      }
+    };
+    stage(smem + L::W1, a.w1f, NTH);
+    stage(smem + L::W2, a.w2f, NTH * NK);
+    stage(smem + L::W3, a.w3f, MAXT * NK);
+    float* b1s = reinterpret_cast<float*>(smem + L::B1);
+    float* b2s = reinterpret_cast<float*>(smem + L::B2);
+    float* b3s = reinterpret_cast<float*>(smem + L::B3);
+    for (int i = threadIdx.x; i < HID; i += nthr) { b1s[i] = a.b1[i]; b2s[i] = a.b2[i]; }
+    for (int i = threadIdx.x; i < 16 * MAXT; i += nthr) b3s[i] = a.b3[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
+  const unsigned l16 = (unsigned)lane * 16u;
+  const float* b1l = reinterpret_cast<const float*>(smem + L::B1);
+  const float* b2l = reinterpret_cast<const float*>(smem + L::B2);
+  const float* b3l = reinterpret_cast<const float*>(smem + L::B3);
+  float* exl = reinterpret_cast<float*>(smem + EXB);
+  u32x4* xh1 = reinterpret_cast<u32x4*>(smem + XH1);
+  u32x4* xh2 = reinterpret_cast<u32x4*>(smem + XH2);
+  const int S = a.nsamples + a.burnin;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // owned bin tiles: the pairs `wave` and `wave + 4` (tiles 2w, 2w+1, 2w+8, 2w+9); wavefront 0 also tile 16
+  auto tile_of = [&](int i) { return i < 4 ? 2 * wave + (i & 1) + 8 * (i >> 1) : 16; };
+  auto own = [&](int i) { return i < 4 || wave == 0; };
+
+  __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(a.VsS, 0, STORE ? (int)a.VsS_bytes : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t zs_rs = __builtin_amdgcn_make_buffer_rsrc(a.Zs, 0, (int)((unsigned)a.NT * (unsigned)a.Rcap * LAT * 4u), 0x00020000);
+  __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(a.src, 0, STORE ? (int)((unsigned)a.NT * (unsigned)a.Rs * 4u) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t acc_rs = __builtin_amdgcn_make_buffer_rsrc(a.acc_out, 0, a.acc_out ? (int)((unsigned)a.NT * (unsigned)S * 4u) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t eps_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.eps), 0, a.eps ? (int)((unsigned)a.NT * (unsigned)S * LAT * 4u) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t x2in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X2), 0, (int)((unsigned)a.NT * (unsigned)a.Fs * 4u), 0x00020000);
+  __amdgpu_buffer_rsrc_t vbin_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Vb), 0, a.Vb ? (int)((unsigned)a.NT * (unsigned)a.Fs * 4u) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, a.W ? (int)((unsigned)a.n_utts * (unsigned)a.Fs * (unsigned)a.Kp * 4u) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Ht), 0, a.Ht ? (int)((unsigned)a.NT * (unsigned)a.Kp * 4u) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t z_rs = __builtin_amdgcn_make_buffer_rsrc(a.Z, 0, (int)((unsigned)a.NT * LAT * 4u), 0x00020000);
+  __amdgpu_buffer_rsrc_t b1in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B1), 0, M2 ? (int)((unsigned)a.NT * HID * 4u) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t u_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u ? (int)((unsigned)a.NT * (unsigned)S * 4u) : 0, 0x00020000);
+
+  for (int wt = blockIdx.x; wt < a.n_wtiles; wt += (int)gridDim.x) {
+    const int utt = a.wt_utt[wt], n0 = a.wt_n0[wt], cnt = a.wt_cnt[wt];
+    const bool fvalid = c < cnt;
+    const int nrow = n0 + (fvalid ? c : cnt - 1);
+    const float gn = a.g[nrow];
+    f32x4 x2[NOWN], vb[NOWN];
+    {
+      const unsigned rowF = (unsigned)nrow * (unsigned)a.Fs, uF = (unsigned)utt * (unsigned)a.Fs;
+#pragma unroll
+      for (int i = 0; i < NOWN; ++i) {
+        x2[i] = f32x4{0, 0, 0, 0};
+        vb[i] = f32x4{1, 1, 1, 1};
+        if (own(i)) {
+          const int t = tile_of(i);
+          const int f0 = t < 16 ? 32 * (t >> 1) + 8 * q + 4 * (t & 1) : 16 * t + 4 * q;      // the chain's bin order (see the file header)
+          f32x4 xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x2in_rs, (rowF + (unsigned)f0) * 4u, 0, 0));
+          f32x4 v = {0, 0, 0, 0};
+          if (a.Vb) {
+            v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vbin_rs, (rowF + (unsigned)f0) * 4u, 0, 0));
+          } else {
+            for (int k = 0; k < a.Kp; k += 4) {          // the same order of operations as wchain_kernel's prologue
+              const f32x4 h4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rs, ((unsigned)nrow * (unsigned)a.Kp + (unsigned)k) * 4u, 0, 0));
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const f32x4 w4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, ((uF + (unsigned)(f0 + j)) * (unsigned)a.Kp + (unsigned)k) * 4u, 0, 0));
+                v[j] += w4[0] * h4[0] + w4[1] * h4[1] + w4[2] * h4[2] + w4[3] * h4[3];
+              }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (f0 + j >= a.F) { xv[j] = 0.f; v[j] = 1.f; }
+          x2[i] = xv;
+          vb[i] = v;
+        }
+      }
+    }
+    f32x4 b1r[2];                                          // M2: layer-1 bias rows of this wavefront's two hidden tiles
+    b1r[0] = b1r[1] = f32x4{0, 0, 0, 0};
+    if (M2) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        // (rounded to bf16 like the rows wchain_kernel parks in LDS at 8 wavefronts: the same bits in both kernels)
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b1in_rs, ((unsigned)nrow * HID + 4u * (unsigned)q) * 4u + 64u * (unsigned)(2 * wave + i), 0, 0));
+        const unsigned w0 = pk2(v[0], v[1]), w1 = pk2(v[2], v[3]);
+        b1r[i] = f32x4{bf_lo(w0), bf_hi(w0), bf_lo(w1), bf_hi(w1)};
+      }
+    }
+    float z[8];
+    {
+      const unsigned zo = ((unsigned)nrow * LAT + 4u * (unsigned)q) * 4u;
+      const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rs, zo, 0, 0));
+      const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rs, zo + 64u, 0, 0));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { z[t] = lo[t]; z[4 + t] = hi[t]; }
+    }
+    // rows: every wavefront writes its own tiles' part; samples, slot map, acceptances and Z: wavefront 0 alone
+    const bool w0 = wave == 0;
+    const unsigned fbase = STORE ? (fvalid ? (unsigned)nrow * (unsigned)(a.Rs * a.Fs) * 2u : WC_OOB) : 0u;
+    const unsigned zs_off = (fvalid && w0) ? ((unsigned)nrow * (unsigned)a.Rcap * LAT + 4u * q) * 4u : WC_OOB;
+    const unsigned fr_off = (fvalid && w0 && q == 0) ? (unsigned)nrow * 4u : WC_OOB;
+    const unsigned rp_off = ((unsigned)nrow * LAT + 4u * q) * 4u;
+    int cur_src = a.nsamples;
+    Xs128 st0, st1;
+    if (a.rng_mode == VAENMF_RNG_DEVICE) {
+      const uint32_t floc = (uint32_t)(nrow - a.frame_off[utt]);
+      st0 = xs_seed(a.utt_seed[utt], floc, (uint32_t)q, a.call);
+      st1 = xs_seed(a.utt_seed[utt], floc, (uint32_t)(4 + q), a.call);
+    }
+
+    auto energy = [&](const float (&zz)[8], int slot, auto dost) -> double {
+      constexpr bool DOST = STORE && decltype(dost)::value;
+      const unsigned voff = DOST ? fbase + (unsigned)slot * (unsigned)a.Fs * 2u : 0u;
+      u32x4 bh[NK], ch[NK];
+      // hidden layers: this wavefront computes feature tiles 2w, 2w+1 -- after tanh and the bf16 rounding exactly k-step w of
+      // the next layer's input fragments (file header) -- and the four k-steps are exchanged through LDS
+      u32x4 mine;
+      auto put2 = [&](int i, const f32x4 h) { mine[2 * i] = pk2(h[0], h[1]); mine[2 * i + 1] = pk2(h[2], h[3]); };
+      auto exchange = [&](u32x4* xh, u32x4 (&dst)[NK]) {
+        xh[wave * 64 + lane] = mine;
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < NK; ++s2) dst[s2] = xh[s2 * 64 + lane];
+      };
+      // one layer, software-pipelined over its output tiles as in wchain_kernel (fragments of tile t+1 requested, MFMAs of
+      // tile t issued, epilogue of tile t-1 computed in one scheduling region)
+      auto run_layer = [&](auto nks_c, auto ntiles_c, auto on, auto frag, auto bias, auto bop, auto epi) {
+        constexpr int NKS = decltype(nks_c)::value, N = decltype(ntiles_c)::value;
+        bf16x8 wh[2][NKS];
+        f32x4 acc[2], bq[2];
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) frag(0, s, wh[0][s]);
+        bq[0] = bias(0);
+#pragma unroll
+        for (int t = 0; t <= N; ++t) {
+          if (t + 1 < N && on(t + 1)) {
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) frag(t + 1, s, wh[(t + 1) & 1][s]);
+            bq[(t + 1) & 1] = bias(t + 1);
+          }
+          if (t < N && on(t)) {
+            f32x4 ac = bq[t & 1];
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t & 1][s], bop(s), ac, 0, 0, 0);
+            acc[t & 1] = ac;
+          }
+          if (t > 0 && on(t - 1)) epi(t - 1, acc[(t - 1) & 1]);
+          if (NKS > 1 && t > 0 && t < N) {
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x400, VN_TPM, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, VN_VPER - VN_TPM, 0);
+            }
+          }
+          VN_SB;
+        }
+      };
+      auto all = [](int) { return true; };
+      bh[0][0] = pk2(zz[0], zz[1]); bh[0][1] = pk2(zz[2], zz[3]); bh[0][2] = pk2(zz[4], zz[5]); bh[0][3] = pk2(zz[6], zz[7]);
+      run_layer(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, all,
+                [&](int i, int, bf16x8& hi) { hi = *reinterpret_cast<const bf16x8*>(smem + L::W1 + (2 * wave + i) * 1024 + l16); },
+                [&](int i) { return M2 ? b1r[i] : *reinterpret_cast<const f32x4*>(b1l + 16 * (2 * wave + i) + 4 * q); },
+                [&](int) { return __builtin_bit_cast(bf16x8, bh[0]); },
+                [&](int i, const f32x4 acc) { put2(i, tanh4(acc)); });
+      exchange(xh1, ch);
+      if (a.one_hidden) {
+#pragma unroll
+        for (int s = 0; s < NK; ++s) bh[s] = ch[s];
+      } else {
+        run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, 2>{}, all,
+                  [&](int i, int s, bf16x8& hi) { hi = *reinterpret_cast<const bf16x8*>(smem + L::W2 + ((2 * wave + i) * NK + s) * 1024 + l16); },
+                  [&](int i) { return *reinterpret_cast<const f32x4*>(b2l + 16 * (2 * wave + i) + 4 * q); },
+                  [&](int s) { return __builtin_bit_cast(bf16x8, ch[s]); },
+                  [&](int i, const f32x4 acc) { put2(i, tanh4(acc)); });
+        exchange(xh2, bh);
+      }
+      // ---- this wavefront's share of the output layer
+      f32x2 pl2 = {0.f, 0.f}, px2 = {0.f, 0.f};
+      float pv[3] = {0.f, 0.f, 0.f};                       // fp32 sums of the pairs `wave`, `wave + 4` and of tile 16
+      unsigned pk_even0 = 0, pk_even1 = 0;
+      run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, NOWN>{}, own,
+                [&](int i, int s, bf16x8& hi) { hi = *reinterpret_cast<const bf16x8*>(smem + L::W3 + (tile_of(i) * NK + s) * 1024 + l16); },
+                [&](int i) { return *reinterpret_cast<const f32x4*>(b3l + 16 * tile_of(i) + 4 * q); },
+                [&](int s) { return __builtin_bit_cast(bf16x8, bh[s]); },
+                [&](int i, const f32x4 acc) {
+                  f32x4 ev;
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) ev[j] = fast_exp(acc[j]);
+                  {
+                    const f32x2 g2 = {gn, gn};
+                    const f32x2 v0 = g2 * ev.lo + vb[i].lo, v1 = g2 * ev.hi + vb[i].hi;
+                    const f32x2 pp = v0 * v1;
+                    pl2 += f32x2{fast_log2(pp[0]), fast_log2(pp[1])};
+                    const f32x2 rc = {fast_rcp(pp[0]), fast_rcp(pp[1])};
+                    px2 = (x2[i].lo * v1 + x2[i].hi * v0) * rc + px2;
+                  }
+                  if (DOST) {
+                    const unsigned p0 = pk2(ev[0], ev[1]), p1 = pk2(ev[2], ev[3]);
+                    const unsigned t = (unsigned)tile_of(i);
+                    if (i < 4) {
+                      if ((i & 1) == 0) { pk_even0 = p0; pk_even1 = p1; }
+                      else __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk_even0, pk_even1, p0, p1}, vrs, voff + 16u * q + 64u * (t >> 1), 0, 0);
+                    } else {
+                      __builtin_amdgcn_raw_buffer_store_b64(u32x2{p0, p1}, vrs, voff + 8u * q + 32u * t, 0, 0);
+                    }
+                  }
+                  if ((i & 1) == 1 || i == 4) {          // fp32 over a pair's two tiles (the odd last tile alone), as wchain_kernel
+                    pv[i >> 1] = (pl2[0] + pl2[1]) * LN2_F + (px2[0] + px2[1]);
+                    pl2 = px2 = f32x2{0.f, 0.f};
+                  }
+                });
+      // ---- exchange: nine fp32 values per lane, added in fp64 in the one-wavefront kernel's order (pairs 0..7, tile 16)
+      // (single buffers: between a read of an exchange area and its next write lie the two other barriers of the evaluation)
+      float* ex = exl + lane;
+      ex[wave * 64] = pv[0];
+      ex[(wave + 4) * 64] = pv[1];
+      if (wave == 0) ex[8 * 64] = pv[2];
+      __syncthreads();
+      double e = 0.0;
+#pragma unroll
+      for (int p = 0; p < 9; ++p) e += (double)ex[p * 64];
+      return sum_rows4_d(e);
+    };
+
+    double Ecur = 0.0;
+    const bool reeval = STORE && a.burnin > 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): retire the prologue's loads (see wchain_kernel)
+    for (int it = -1; it < S + (reeval ? 1 : 0); ++it) {
+      asm volatile("" ::: "memory");
+      const bool re = reeval && it == a.burnin;
+      const int m = (reeval && it > a.burnin) ? it - 1 : it;
+      const bool step = m >= 0 && !re;
+      float zp[8];
+      float lu = 0.f;
+      if (step) {
+        if (a.rng_mode == VAENMF_RNG_DEVICE) {
+          const f32x4 e0 = normal4(st0);
+          const float uu = q == 0 ? uniform01(st0) : 0.5f;
+          const f32x4 e1 = normal4(st1);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { zp[t] = z[t] + a.sd * e0[t]; zp[4 + t] = z[4 + t] + a.sd_hi * e1[t]; }
+          lu = q == 0 ? fast_log(uu) : 0.f;
+        } else {
+          const unsigned so = (unsigned)m * (unsigned)a.NT;
+          const f32x4 e0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(eps_rs, rp_off + so * (LAT * 4u), 0, 0));
+          const f32x4 e1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(eps_rs, rp_off + so * (LAT * 4u) + 64u, 0, 0));
+          const float uu = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(u_rs, (unsigned)nrow * 4u + so * 4u, 0, 0));
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { zp[t] = z[t] + a.sd * e0[t]; zp[4 + t] = z[4 + t] + a.sd_hi * e1[t]; }
+          lu = q == 0 ? fast_log(uu) : 0.f;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(zp[t]));
+          asm volatile("" : "+v"(lu));
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) zp[t] = z[t];
+      }
+      const int slot = !STORE ? -1 : (re ? a.nsamples : (m >= a.burnin ? m - a.burnin : ((m < 0 && a.burnin == 0) ? a.nsamples : -1)));
+      double Ep;
+      if (STORE && slot >= 0) Ep = energy(zp, slot, std::true_type{});
+      else Ep = energy(zp, slot, std::false_type{});
+      if (re) continue;
+      float pr = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pr += z[j] * z[j] - zp[j] * zp[j];
+      pr = sum_rows4(pr);
+      lu = sum_rows4(lu);
+      const float accp = (float)(Ecur - Ep) + 0.5f * pr;
+      const bool ok = m < 0 || lu < accp;
+      if (a.acc_out && m >= 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, accp), acc_rs, fr_off + (unsigned)m * (unsigned)a.NT * 4u, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = ok ? zp[j] : z[j];
+      Ecur = ok ? Ep : Ecur;
+      if (m >= a.burnin) {
+        const unsigned r = (unsigned)(m - a.burnin);
+        if (STORE) {
+          cur_src = ok ? (int)r : cur_src;
+          __builtin_amdgcn_raw_buffer_store_b32((unsigned)cur_src, src_rs, fr_off + r * (unsigned)a.NT * 4u, 0, 0);
+        }
+        const unsigned zo = zs_off + r * (LAT * 4u);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{z[0], z[1], z[2], z[3]}), zs_rs, zo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{z[4], z[5], z[6], z[7]}), zs_rs, zo + 64u, 0, 0);
+      }
+    }
+    if (a.update_Z) {
+      const unsigned zo = (fvalid && w0) ? rp_off : WC_OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{z[0], z[1], z[2], z[3]}), z_rs, zo, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{z[4], z[5], z[6], z[7]}), z_rs, zo + 64u, 0, 0);
+    }
+  }
+}
+
 }  // namespace
 
 // ============================================================================
@@ -667,6 +989,12 @@ int wc_launch_s(const WcArgs& a, int nwt, int n_sms, size_t lds, hipStream_t st)
 }
 
 }  // namespace
+
+// dev / test switch: VAENMF_WCHAIN4=0 keeps small batches on wchain_kernel (read per call)
+static bool wc4_enabled() {
+  const char* e = getenv("VAENMF_WCHAIN4");
+  return !(e && e[0] == '0');
+}
 
 // Shapes the wave-private chain covers (the rest runs engine.hip's team kernel): every W3 hi fragment in LDS
 bool vn_wchain_supported(const vaenmf_plan* p) {
@@ -719,6 +1047,22 @@ int vn_launch_wchain(vaenmf_plan* p, const VnChainCall& cc, hipStream_t st) {
   a.b1_lds = (int)(fixed + w3hi * (lol ? 2 : 1));
   const size_t lds = (size_t)a.b1_lds + ((cc.B1 && nwaves == 8) ? (size_t)nwaves * NTH * 512 : 0);
   VN_REQUIRE(lds <= (size_t)WC_LDS_LIMIT, "wave chain: %zu bytes of LDS needed", lds);
+  // small batches in the bench shape: four wavefronts per wave tile (wchain4_kernel), one workgroup per CU
+  if (!split && p->NT3c == 17 && p->n_wtiles <= p->n_sms && wc4_enabled()) {
+    const size_t lds4 = (size_t)WcLds<false>::W3 + 17 * NK * 1024 + 2 * 4 * 64 * 16 + 12 * 64 * 4;
+    const int grid = p->n_wtiles;
+    auto go = [&](auto* fn) -> int {
+      if (int e = vn_ensure_dyn_lds((const void*)fn, WC_LDS_LIMIT)) return e;
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds4, st, a);
+      return 0;
+    };
+    int rc4 = cc.B1 ? (a.VsS ? go(wchain4_kernel<true, true>) : go(wchain4_kernel<false, true>))
+                    : (a.VsS ? go(wchain4_kernel<true, false>) : go(wchain4_kernel<false, false>));
+    if (rc4) return rc4;
+    VN_CHECK_HIP(hipGetLastError());
+    p->last_chain_kernel = 2;
+    return 0;
+  }
   // wavefronts per workgroup: 8 (two per SIMD, 256 registers each) in bf16 mode, 4 (512 registers) in bf16x3 mode
   int rc = -1;
   if (p->NT3c == 33)     rc = wc_launch_s<33, true, false, 4, false, GT33>(a, p->n_wtiles, p->n_sms, lds, st);
@@ -731,6 +1075,7 @@ int vn_launch_wchain(vaenmf_plan* p, const VnChainCall& cc, hipStream_t st) {
   VN_REQUIRE(rc != -1, "wave chain: shape not compiled in (dev build)");
   if (rc) return rc;
   VN_CHECK_HIP(hipGetLastError());
+  p->last_chain_kernel = 1;
   return 0;
 }
 

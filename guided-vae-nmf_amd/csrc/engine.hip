@@ -1477,6 +1477,7 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
   }
   if (lrc) return lrc;
   VN_CHECK_HIP(hipGetLastError());
+  p->last_chain_kernel = 0;
   if (p->store_on) { p->store_R = nsamples; p->store_Rs = nsamples + 1; }
   return 0;
 }

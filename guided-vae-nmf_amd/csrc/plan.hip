@@ -199,6 +199,7 @@ extern "C" int vaenmf_plan_query(const vaenmf_plan* p, int32_t what) {
     case VAENMF_Q_EM_GRAPH: return p->last_em_graph;
     case VAENMF_Q_DEV_ALLOCS: return (int)g_vn_dev_allocs;
     case VAENMF_Q_W_FUSED: return p->last_w_fused;
+    case VAENMF_Q_CHAIN_KERNEL: return p->last_chain_kernel;
     default: return -1;
   }
 }

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("VAENMF_LIB") or os.path.join(_HERE, "libvaenmf.so")  
 
 PREC_BF16X3, PREC_BF16 = 0, 1
 RNG_REPLAY, RNG_DEVICE = 0, 1
-Q_FS, Q_KP, Q_TILES, Q_NT, Q_NUTT, Q_MSTEP_PATH, Q_WTILES, Q_EM_GRAPH, Q_DEV_ALLOCS, Q_W_FUSED = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+Q_FS, Q_KP, Q_TILES, Q_NT, Q_NUTT, Q_MSTEP_PATH, Q_WTILES, Q_EM_GRAPH, Q_DEV_ALLOCS, Q_W_FUSED, Q_CHAIN_KERNEL = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID, ACT_STEP = 0, 1, 2, 3, 4
 LABEL_IBM, LABEL_VAD = 0, 1
 

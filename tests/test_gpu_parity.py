@@ -1445,3 +1445,61 @@ def test_tiny_and_ragged_utterances_against_the_oracle(counts, prec):
         assert rel_err(WFs[sl, :F].cpu().numpy().T, o["WFs"]) < 5e-3
         sh = np.ascontiguousarray(Sh[sl, :F].cpu().numpy()).view(np.complex64).reshape(counts[i], F).T
         assert nrm_err(sh, o["WFs"] * o["o"].X) < 2e-3
+
+
+@pytest.mark.parametrize("model,rng", [("M1", "device"), ("M2", "device"), ("M1", "replay")])
+def test_four_wavefront_chain_equals_the_wave_chain_bit_for_bit(model, rng):
+    """Small batches of the bench shape (at most one 16-frame wave tile per CU: one utterance through the drop-in classes)
+    run wchain4_kernel -- four wavefronts per tile, each owning two of the output layer's eight bin-tile pairs, the pair
+    energies exchanged through LDS and added in the one-wavefront kernel's order.  Same proposals, same log-acceptances,
+    same decisions, same samples, same stored rows as wchain_kernel, bit for bit (mcem.py:371-441) -- ragged utterances
+    (tiles of 16, 1, 5 frames), store on, a chain with burn-in and one without, then the M-step over both stores."""
+    need_gpu()
+    from vaenmf import _lib
+    F, K, R, BI = 257, 8, 30, 30
+    counts = [33, 17, 5]
+    NT = sum(counts)
+    ydim = F if model == "M2" else 0
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=5, y_dim=ydim, bias_std=0.05)
+    g = np.random.default_rng(7)
+    Xs = [((g.standard_normal((n, F)) + 1j * g.standard_normal((n, F))) * (0.5 + 3 * np.exp(-np.arange(F) / 60.0))).astype(np.complex64) for n in counts]
+    W0 = [np.maximum(g.random((F, K)), 1e-8).astype(np.float32) for _ in counts]
+    H0 = [np.maximum(g.random((K, n)), 1e-8).astype(np.float32) for n in counts]
+    gains = (0.5 + g.random(NT)).astype(np.float32)
+    Z0 = (0.5 * g.standard_normal((NT, 32))).astype(np.float32)
+    y = (g.random((NT, F)) > 0.5).astype(np.float32)
+    eps = g.standard_normal((R + BI, NT, 32)).astype(np.float32)
+    u = g.random((R + BI, NT)).astype(np.float32)
+
+    def run(four):
+        os.environ["VAENMF_WCHAIN4"] = "1" if four else "0"
+        try:
+            eng = make_engine(params, F, K, counts, Rcap=R, precision="bf16", seeds=[11, 12, 13])
+            dev = eng.device
+            eng.set_spectrogram(Xs)
+            eng.init_nmf(W0, H0)
+            eng.g.copy_(torch.from_numpy(gains))
+            if model == "M2":
+                eng.set_labels(torch.from_numpy(y))
+            eng.Z.copy_(torch.from_numpy(Z0))
+            eng.sample_store(True)
+            kw = dict(eps=torch.from_numpy(eps).to(dev), u=torch.from_numpy(u).to(dev)) if rng == "replay" else dict(call=3)
+            out = []
+            acc = eng.mh_chain(R, BI, 0.01, want_acc=True, **kw)
+            assert _lib.lib().vaenmf_plan_query(eng._plan, _lib.Q_CHAIN_KERNEL) == (2 if four else 1)
+            out += [acc.cpu().numpy().copy(), eng.Zs[:, :R].cpu().numpy().copy(), eng.Z.cpu().numpy().copy(), eng.stored_variances(R).cpu().numpy().copy()]
+            c = eng.m_step_stored().clone()
+            out += [t.cpu().numpy().copy() for t in (eng.W, eng.Ht, eng.g, c)]
+            # a chain without burn-in (slot R holds the initial state), Z not updated: the Wiener chain's form
+            kw2 = dict(eps=kw["eps"][:R], u=kw["u"][:R]) if rng == "replay" else dict(call=4)
+            eng.mh_chain(R, 0, 0.01, update_Z=False, **kw2)
+            out += [eng.Zs[:, :R].cpu().numpy().copy(), eng.Z.cpu().numpy().copy(), eng.stored_variances(R).cpu().numpy().copy()]
+            return out
+        finally:
+            os.environ.pop("VAENMF_WCHAIN4", None)
+
+    a, b = run(True), run(False)
+    names = ("acc", "Zs", "Z", "rows", "W", "Ht", "g", "cost", "Zs2", "Z2", "rows2")
+    assert np.abs(a[1] - Z0[:, None, :]).max() > 0.05            # the chains moved
+    for x, yv, name in zip(a, b, names):
+        assert np.array_equal(x, yv), name

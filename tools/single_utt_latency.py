@@ -6,11 +6,12 @@ import numpy as np, torch
 import vaenmf
 from vaenmf import stft as vstft
 from vaenmf.synth import synth_utterance, xavier_normal_params
-F, K, NITER = 257, 8, 100
+NFFT = int(os.environ.get("NFFT", "512"))
+F, K, NITER = NFFT // 2 + 1, int(os.environ.get("RANK", "8")), 100
 vae = vaenmf.VariationalAutoencoder([F, 32, [128, 128]])
 vae.load_state_dict({k: torch.tensor(v) for k, v in xavier_normal_params([F, 32, [128, 128]], seed=0).items()})
 x = synth_utterance(0)[2]
-X = vstft.stft(x, fs=16000, wlen_sec=32e-3, hop_percent=0.25).T
+X = vstft.stft(x, fs=16000, wlen_sec=NFFT / 16000, hop_percent=0.25).T
 m = vaenmf.MCEM_M1(niter=NITER, rng="device", precision=sys.argv[1] if len(sys.argv) > 1 else "bf16", fused_store=(os.environ.get("FUSED_STORE", "1") == "1"))
 ts = []
 for k in range(5):
