@@ -639,47 +639,52 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
 // result -- are bit-identical to wchain_kernel's (tested).  Three workgroup barriers per evaluation.  A lone wavefront per
 // SIMD needed 7 450 cycles per evaluation for the whole decoder.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool STORE, bool M2>
+template <int MAXT, bool STORE, bool M2>
 __global__ __launch_bounds__(256, 1) void wchain4_kernel(const WcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using L = WcLds<false>;
-  constexpr int MAXT = 17, NOWN = 5, NWV = 4;
-  constexpr int XH1 = L::W3 + MAXT * NK * 1024;          // exchange areas: hidden activations u32x4 [4][64] per hidden layer,
-  constexpr int XH2 = XH1 + 4 * 64 * 16;                 // pair energies float [12][64]
-  constexpr int EXB = XH2 + 4 * 64 * 16;
-  {
-    const int nthr = NWV * 64;
-    auto stage = [&](char* dst, const __bf16* srcp, int nblk) {    // hi blocks [blk][2 parts] -> [blk]
-      for (int e = threadIdx.x; e < nblk * 64; e += nthr) {
-        const int chunk = e & 63, b = e >> 6;
-        *reinterpret_cast<f32x4*>(dst + (size_t)e * 16) =
-            *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(srcp) + ((size_t)(b * 2) * 64 + chunk) * 16);
-      }
-    };
-    stage(smem + L::W1, a.w1f, NTH);
-    stage(smem + L::W2, a.w2f, NTH * NK);
-    stage(smem + L::W3, a.w3f, MAXT * NK);
-    float* b1s = reinterpret_cast<float*>(smem + L::B1);
-    float* b2s = reinterpret_cast<float*>(smem + L::B2);
-    float* b3s = reinterpret_cast<float*>(smem + L::B3);
-    for (int i = threadIdx.x; i < HID; i += nthr) { b1s[i] = a.b1[i]; b2s[i] = a.b2[i]; }
-    for (int i = threadIdx.x; i < 16 * MAXT; i += nthr) b3s[i] = a.b3[i];
-  }
-  __syncthreads();
+  constexpr int NP = (MAXT - 1) / 2;                     // bin-tile pairs (8 / 16); tile MAXT-1 is the odd last one
+  constexpr int PPW = NP / 4, NOWN = 2 * PPW + 1;        // pairs and tiles per wavefront (wavefront 0 owns the last tile too)
+  constexpr bool B1BF = MAXT == 17;                      // M2 bias rows as wchain_kernel holds them for this shape (bf16 at 8 wavefronts, fp32 at 4)
+  static_assert(NP % 4 == 0, "pairs must split over four wavefronts");
+  // LDS: exchange areas only -- hidden activations u32x4 [4][64] per hidden layer, pair energies float [NP + 1][64]
+  u32x4* xh1 = reinterpret_cast<u32x4*>(smem);
+  u32x4* xh2 = xh1 + 4 * 64;
+  float* exl = reinterpret_cast<float*>(xh2 + 4 * 64);
 
   const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
   const unsigned l16 = (unsigned)lane * 16u;
-  const float* b1l = reinterpret_cast<const float*>(smem + L::B1);
-  const float* b2l = reinterpret_cast<const float*>(smem + L::B2);
-  const float* b3l = reinterpret_cast<const float*>(smem + L::B3);
-  float* exl = reinterpret_cast<float*>(smem + EXB);
-  u32x4* xh1 = reinterpret_cast<u32x4*>(smem + XH1);
-  u32x4* xh2 = reinterpret_cast<u32x4*>(smem + XH2);
   const int S = a.nsamples + a.burnin;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // owned bin tiles: the pairs `wave` and `wave + 4` (tiles 2w, 2w+1, 2w+8, 2w+9); wavefront 0 also tile 16
-  auto tile_of = [&](int i) { return i < 4 ? 2 * wave + (i & 1) + 8 * (i >> 1) : 16; };
-  auto own = [&](int i) { return i < 4 || wave == 0; };
+  // owned bin tiles: the pairs wave, wave + 4, ... (tiles 2p, 2p+1); wavefront 0 also tile MAXT-1
+  auto tile_of = [&](int i) { return i < 2 * PPW ? 2 * (wave + 4 * (i >> 1)) + (i & 1) : MAXT - 1; };
+  auto own = [&](int i) { return i < 2 * PPW || wave == 0; };
+
+  // ---- this wavefront's weight fragments and biases, in registers for the whole launch (fragment order
+  // [tile][kstep][hi/lo][lane][8], plan.hip): 2 hidden tiles per hidden layer, NOWN bin tiles -- no LDS-resident weights,
+  // no weight loads inside the chain
+  bf16x8 w1r[2], w2r[2][NK], w3r[NOWN][NK];
+  f32x4 bias1[2], bias2[2], bias3[NOWN];
+  {
+    const char* w1g = reinterpret_cast<const char*>(a.w1f);
+    const char* w2g = reinterpret_cast<const char*>(a.w2f);
+    const char* w3g = reinterpret_cast<const char*>(a.w3f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = 2 * wave + i;
+      w1r[i] = *reinterpret_cast<const bf16x8*>(w1g + (size_t)(t * 2) * 1024 + l16);
+#pragma unroll
+      for (int s = 0; s < NK; ++s) w2r[i][s] = *reinterpret_cast<const bf16x8*>(w2g + (size_t)((t * NK + s) * 2) * 1024 + l16);
+      bias1[i] = *reinterpret_cast<const f32x4*>(a.b1 + 16 * t + 4 * q);
+      bias2[i] = *reinterpret_cast<const f32x4*>(a.b2 + 16 * t + 4 * q);
+    }
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) {
+      const int t = tile_of(i);
+#pragma unroll
+      for (int s = 0; s < NK; ++s) w3r[i][s] = *reinterpret_cast<const bf16x8*>(w3g + (size_t)((t * NK + s) * 2) * 1024 + l16);
+      bias3[i] = *reinterpret_cast<const f32x4*>(a.b3 + 16 * t + 4 * q);
+    }
+  }
 
   __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(a.VsS, 0, STORE ? (int)a.VsS_bytes : 0, 0x00020000);
   __amdgpu_buffer_rsrc_t zs_rs = __builtin_amdgcn_make_buffer_rsrc(a.Zs, 0, (int)((unsigned)a.NT * (unsigned)a.Rcap * LAT * 4u), 0x00020000);
@@ -708,7 +713,7 @@ __global__ __launch_bounds__(256, 1) void wchain4_kernel(const WcArgs a) {
         vb[i] = f32x4{1, 1, 1, 1};
         if (own(i)) {
           const int t = tile_of(i);
-          const int f0 = t < 16 ? 32 * (t >> 1) + 8 * q + 4 * (t & 1) : 16 * t + 4 * q;      // the chain's bin order (see the file header)
+          const int f0 = t < MAXT - 1 ? 32 * (t >> 1) + 8 * q + 4 * (t & 1) : 16 * t + 4 * q;      // the chain's bin order (see the file header)
           f32x4 xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x2in_rs, (rowF + (unsigned)f0) * 4u, 0, 0));
           f32x4 v = {0, 0, 0, 0};
           if (a.Vb) {
@@ -731,15 +736,16 @@ __global__ __launch_bounds__(256, 1) void wchain4_kernel(const WcArgs a) {
         }
       }
     }
-    f32x4 b1r[2];                                          // M2: layer-1 bias rows of this wavefront's two hidden tiles
-    b1r[0] = b1r[1] = f32x4{0, 0, 0, 0};
+    f32x4 b1r[2];                                          // layer-1 accumulator init of this wavefront's two hidden tiles
+    b1r[0] = bias1[0]; b1r[1] = bias1[1];
     if (M2) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        // (rounded to bf16 like the rows wchain_kernel parks in LDS at 8 wavefronts: the same bits in both kernels)
         const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b1in_rs, ((unsigned)nrow * HID + 4u * (unsigned)q) * 4u + 64u * (unsigned)(2 * wave + i), 0, 0));
-        const unsigned w0 = pk2(v[0], v[1]), w1 = pk2(v[2], v[3]);
-        b1r[i] = f32x4{bf_lo(w0), bf_hi(w0), bf_lo(w1), bf_hi(w1)};
+        if (B1BF) {      // (rounded to bf16 like the rows wchain_kernel parks in LDS at 8 wavefronts: the same bits in both kernels)
+          const unsigned w0 = pk2(v[0], v[1]), w1 = pk2(v[2], v[3]);
+          b1r[i] = f32x4{bf_lo(w0), bf_hi(w0), bf_lo(w1), bf_hi(w1)};
+        } else b1r[i] = v;
       }
     }
     float z[8];
@@ -778,104 +784,89 @@ __global__ __launch_bounds__(256, 1) void wchain4_kernel(const WcArgs a) {
 #pragma unroll
         for (int s2 = 0; s2 < NK; ++s2) dst[s2] = xh[s2 * 64 + lane];
       };
-      // one layer, software-pipelined over its output tiles as in wchain_kernel (fragments of tile t+1 requested, MFMAs of
-      // tile t issued, epilogue of tile t-1 computed in one scheduling region)
-      auto run_layer = [&](auto nks_c, auto ntiles_c, auto on, auto frag, auto bias, auto bop, auto epi) {
-        constexpr int NKS = decltype(nks_c)::value, N = decltype(ntiles_c)::value;
-        bf16x8 wh[2][NKS];
-        f32x4 acc[2], bq[2];
+      {
+        const bf16x8 zin = __builtin_bit_cast(bf16x8, u32x4{pk2(zz[0], zz[1]), pk2(zz[2], zz[3]), pk2(zz[4], zz[5]), pk2(zz[6], zz[7])});
+        f32x4 ac[2];
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) frag(0, s, wh[0][s]);
-        bq[0] = bias(0);
+        for (int i = 0; i < 2; ++i) ac[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[i], zin, b1r[i], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t <= N; ++t) {
-          if (t + 1 < N && on(t + 1)) {
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) frag(t + 1, s, wh[(t + 1) & 1][s]);
-            bq[(t + 1) & 1] = bias(t + 1);
-          }
-          if (t < N && on(t)) {
-            f32x4 ac = bq[t & 1];
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t & 1][s], bop(s), ac, 0, 0, 0);
-            acc[t & 1] = ac;
-          }
-          if (t > 0 && on(t - 1)) epi(t - 1, acc[(t - 1) & 1]);
-          if (NKS > 1 && t > 0 && t < N) {
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x400, VN_TPM, 0);
-              __builtin_amdgcn_sched_group_barrier(0x002, VN_VPER - VN_TPM, 0);
-            }
-          }
-          VN_SB;
-        }
-      };
-      auto all = [](int) { return true; };
-      bh[0][0] = pk2(zz[0], zz[1]); bh[0][1] = pk2(zz[2], zz[3]); bh[0][2] = pk2(zz[4], zz[5]); bh[0][3] = pk2(zz[6], zz[7]);
-      run_layer(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, all,
-                [&](int i, int, bf16x8& hi) { hi = *reinterpret_cast<const bf16x8*>(smem + L::W1 + (2 * wave + i) * 1024 + l16); },
-                [&](int i) { return M2 ? b1r[i] : *reinterpret_cast<const f32x4*>(b1l + 16 * (2 * wave + i) + 4 * q); },
-                [&](int) { return __builtin_bit_cast(bf16x8, bh[0]); },
-                [&](int i, const f32x4 acc) { put2(i, tanh4(acc)); });
+        for (int i = 0; i < 2; ++i) put2(i, tanh4(ac[i]));
+      }
       exchange(xh1, ch);
       if (a.one_hidden) {
 #pragma unroll
         for (int s = 0; s < NK; ++s) bh[s] = ch[s];
       } else {
-        run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, 2>{}, all,
-                  [&](int i, int s, bf16x8& hi) { hi = *reinterpret_cast<const bf16x8*>(smem + L::W2 + ((2 * wave + i) * NK + s) * 1024 + l16); },
-                  [&](int i) { return *reinterpret_cast<const f32x4*>(b2l + 16 * (2 * wave + i) + 4 * q); },
-                  [&](int s) { return __builtin_bit_cast(bf16x8, ch[s]); },
-                  [&](int i, const f32x4 acc) { put2(i, tanh4(acc)); });
+        f32x4 ac[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ac[i] = bias2[i];
+#pragma unroll
+          for (int s = 0; s < NK; ++s) ac[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2r[i][s], __builtin_bit_cast(bf16x8, ch[s]), ac[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) put2(i, tanh4(ac[i]));
         exchange(xh2, bh);
       }
-      // ---- this wavefront's share of the output layer
+      // ---- this wavefront's share of the output layer: tile i+1's MFMAs are issued before tile i's epilogue
       f32x2 pl2 = {0.f, 0.f}, px2 = {0.f, 0.f};
-      float pv[3] = {0.f, 0.f, 0.f};                       // fp32 sums of the pairs `wave`, `wave + 4` and of tile 16
-      unsigned pk_even0 = 0, pk_even1 = 0;
-      run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, NOWN>{}, own,
-                [&](int i, int s, bf16x8& hi) { hi = *reinterpret_cast<const bf16x8*>(smem + L::W3 + (tile_of(i) * NK + s) * 1024 + l16); },
-                [&](int i) { return *reinterpret_cast<const f32x4*>(b3l + 16 * tile_of(i) + 4 * q); },
-                [&](int s) { return __builtin_bit_cast(bf16x8, bh[s]); },
-                [&](int i, const f32x4 acc) {
-                  f32x4 ev;
+      float pv[PPW + 1];
 #pragma unroll
-                  for (int j = 0; j < 4; ++j) ev[j] = fast_exp(acc[j]);
-                  {
-                    const f32x2 g2 = {gn, gn};
-                    const f32x2 v0 = g2 * ev.lo + vb[i].lo, v1 = g2 * ev.hi + vb[i].hi;
-                    const f32x2 pp = v0 * v1;
-                    pl2 += f32x2{fast_log2(pp[0]), fast_log2(pp[1])};
-                    const f32x2 rc = {fast_rcp(pp[0]), fast_rcp(pp[1])};
-                    px2 = (x2[i].lo * v1 + x2[i].hi * v0) * rc + px2;
-                  }
-                  if (DOST) {
-                    const unsigned p0 = pk2(ev[0], ev[1]), p1 = pk2(ev[2], ev[3]);
-                    const unsigned t = (unsigned)tile_of(i);
-                    if (i < 4) {
-                      if ((i & 1) == 0) { pk_even0 = p0; pk_even1 = p1; }
-                      else __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk_even0, pk_even1, p0, p1}, vrs, voff + 16u * q + 64u * (t >> 1), 0, 0);
-                    } else {
-                      __builtin_amdgcn_raw_buffer_store_b64(u32x2{p0, p1}, vrs, voff + 8u * q + 32u * t, 0, 0);
-                    }
-                  }
-                  if ((i & 1) == 1 || i == 4) {          // fp32 over a pair's two tiles (the odd last tile alone), as wchain_kernel
-                    pv[i >> 1] = (pl2[0] + pl2[1]) * LN2_F + (px2[0] + px2[1]);
-                    pl2 = px2 = f32x2{0.f, 0.f};
-                  }
-                });
-      // ---- exchange: nine fp32 values per lane, added in fp64 in the one-wavefront kernel's order (pairs 0..7, tile 16)
+      for (int j = 0; j <= PPW; ++j) pv[j] = 0.f;
+      unsigned pk_even0 = 0, pk_even1 = 0;
+      auto mm3 = [&](int i) {
+        f32x4 ac = bias3[i];
+#pragma unroll
+        for (int s = 0; s < NK; ++s) ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3r[i][s], __builtin_bit_cast(bf16x8, bh[s]), ac, 0, 0, 0);
+        return ac;
+      };
+      auto epi = [&](int i, const f32x4 acc) {
+        f32x4 ev;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ev[j] = fast_exp(acc[j]);
+        {
+          // two bins at a time, exactly as wchain_kernel's epilogue
+          const f32x2 g2 = {gn, gn};
+          const f32x2 v0 = g2 * ev.lo + vb[i].lo, v1 = g2 * ev.hi + vb[i].hi;
+          const f32x2 pp = v0 * v1;
+          pl2 += f32x2{fast_log2(pp[0]), fast_log2(pp[1])};
+          const f32x2 rc = {fast_rcp(pp[0]), fast_rcp(pp[1])};
+          px2 = (x2[i].lo * v1 + x2[i].hi * v0) * rc + px2;
+        }
+        if (DOST) {
+          const unsigned p0 = pk2(ev[0], ev[1]), p1 = pk2(ev[2], ev[3]);
+          const unsigned t = (unsigned)tile_of(i);
+          if (i < 2 * PPW) {
+            if ((i & 1) == 0) { pk_even0 = p0; pk_even1 = p1; }
+            else __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk_even0, pk_even1, p0, p1}, vrs, voff + 16u * q + 64u * (t >> 1), 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{p0, p1}, vrs, voff + 8u * q + 32u * t, 0, 0);
+          }
+        }
+        if ((i & 1) == 1 || i == 2 * PPW) {     // fp32 over a pair's two tiles (the odd last tile alone), as wchain_kernel
+          pv[i >> 1] = (pl2[0] + pl2[1]) * LN2_F + (px2[0] + px2[1]);
+          pl2 = px2 = f32x2{0.f, 0.f};
+        }
+      };
+      {
+        f32x4 acn = mm3(0);
+#pragma unroll
+        for (int i = 0; i < NOWN; ++i) {
+          const f32x4 acc = acn;
+          if (i + 1 < NOWN && own(i + 1)) acn = mm3(i + 1);
+          if (own(i)) epi(i, acc);
+        }
+      }
+      // ---- exchange: NP + 1 fp32 values per lane, added in fp64 in the one-wavefront kernel's order (pairs 0.., last tile)
       // (single buffers: between a read of an exchange area and its next write lie the two other barriers of the evaluation)
       float* ex = exl + lane;
-      ex[wave * 64] = pv[0];
-      ex[(wave + 4) * 64] = pv[1];
-      if (wave == 0) ex[8 * 64] = pv[2];
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) ex[(wave + 4 * j) * 64] = pv[j];
+      if (wave == 0) ex[NP * 64] = pv[PPW];
       __syncthreads();
       double e = 0.0;
 #pragma unroll
-      for (int p = 0; p < 9; ++p) e += (double)ex[p * 64];
+      for (int p = 0; p <= NP; ++p) e += (double)ex[p * 64];
       return sum_rows4_d(e);
     };
 
@@ -883,7 +874,6 @@ __global__ __launch_bounds__(256, 1) void wchain4_kernel(const WcArgs a) {
     const bool reeval = STORE && a.burnin > 0;
     __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): retire the prologue's loads (see wchain_kernel)
     for (int it = -1; it < S + (reeval ? 1 : 0); ++it) {
-      asm volatile("" ::: "memory");
       const bool re = reeval && it == a.burnin;
       const int m = (reeval && it > a.burnin) ? it - 1 : it;
       const bool step = m >= 0 && !re;
@@ -1047,17 +1037,22 @@ int vn_launch_wchain(vaenmf_plan* p, const VnChainCall& cc, hipStream_t st) {
   a.b1_lds = (int)(fixed + w3hi * (lol ? 2 : 1));
   const size_t lds = (size_t)a.b1_lds + ((cc.B1 && nwaves == 8) ? (size_t)nwaves * NTH * 512 : 0);
   VN_REQUIRE(lds <= (size_t)WC_LDS_LIMIT, "wave chain: %zu bytes of LDS needed", lds);
-  // small batches in the bench shape: four wavefronts per wave tile (wchain4_kernel), one workgroup per CU
-  if (!split && p->NT3c == 17 && p->n_wtiles <= p->n_sms && wc4_enabled()) {
-    const size_t lds4 = (size_t)WcLds<false>::W3 + 17 * NK * 1024 + 2 * 4 * 64 * 16 + 12 * 64 * 4;
+  // small batches (at most one wave tile per CU) in bf16 mode at 17 / 33 bin tiles: four wavefronts per wave tile (wchain4_kernel)
+  if (!split && (p->NT3c == 17 || p->NT3c == 33) && p->n_wtiles <= p->n_sms && wc4_enabled()) {
+    const size_t lds4 = 2 * 4 * 64 * 16 + 20 * 64 * 4;          // exchange areas only
     const int grid = p->n_wtiles;
     auto go = [&](auto* fn) -> int {
-      if (int e = vn_ensure_dyn_lds((const void*)fn, WC_LDS_LIMIT)) return e;
       hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds4, st, a);
       return 0;
     };
-    int rc4 = cc.B1 ? (a.VsS ? go(wchain4_kernel<true, true>) : go(wchain4_kernel<false, true>))
-                    : (a.VsS ? go(wchain4_kernel<true, false>) : go(wchain4_kernel<false, false>));
+    a.w3f = p->w3c; a.b3 = p->b3c;
+    int rc4;
+    if (p->NT3c == 17)
+      rc4 = cc.B1 ? (a.VsS ? go(wchain4_kernel<17, true, true>) : go(wchain4_kernel<17, false, true>))
+                  : (a.VsS ? go(wchain4_kernel<17, true, false>) : go(wchain4_kernel<17, false, false>));
+    else
+      rc4 = cc.B1 ? (a.VsS ? go(wchain4_kernel<33, true, true>) : go(wchain4_kernel<33, false, true>))
+                  : (a.VsS ? go(wchain4_kernel<33, true, false>) : go(wchain4_kernel<33, false, false>));
     if (rc4) return rc4;
     VN_CHECK_HIP(hipGetLastError());
     p->last_chain_kernel = 2;

@@ -1447,16 +1447,18 @@ def test_tiny_and_ragged_utterances_against_the_oracle(counts, prec):
         assert nrm_err(sh, o["WFs"] * o["o"].X) < 2e-3
 
 
-@pytest.mark.parametrize("model,rng", [("M1", "device"), ("M2", "device"), ("M1", "replay")])
-def test_four_wavefront_chain_equals_the_wave_chain_bit_for_bit(model, rng):
+@pytest.mark.parametrize("F,K,model,rng", [(257, 8, "M1", "device"), (257, 8, "M2", "device"), (257, 8, "M1", "replay"),
+                                           (513, 10, "M1", "device"), (513, 10, "M2", "device"), (513, 32, "M1", "replay")])
+def test_four_wavefront_chain_equals_the_wave_chain_bit_for_bit(F, K, model, rng):
     """Small batches of the bench shape (at most one 16-frame wave tile per CU: one utterance through the drop-in classes)
     run wchain4_kernel -- four wavefronts per tile, each owning two of the output layer's eight bin-tile pairs, the pair
     energies exchanged through LDS and added in the one-wavefront kernel's order.  Same proposals, same log-acceptances,
     same decisions, same samples, same stored rows as wchain_kernel, bit for bit (mcem.py:371-441) -- ragged utterances
-    (tiles of 16, 1, 5 frames), store on, a chain with burn-in and one without, then the M-step over both stores."""
+    (tiles of 16, 1, 5 frames), store on, a chain with burn-in and one without, then the M-step over both stores; the bench
+    shape (17 bin tiles) and the reference scripts' 1024-pt STFT (33 bin tiles, four pairs per wavefront)."""
     need_gpu()
     from vaenmf import _lib
-    F, K, R, BI = 257, 8, 30, 30
+    R, BI = 30, 30
     counts = [33, 17, 5]
     NT = sum(counts)
     ydim = F if model == "M2" else 0
