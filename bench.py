@@ -466,26 +466,35 @@ def main():
             import vaenmf
             from vaenmf import stft as vstft
             note("config 1 on the GPU: one utterance through MCEM_M1.init_parameters / run")
-            vae = vaenmf.VariationalAutoencoder([F, 32, [128, 128]])
-            vae.load_state_dict({k: torch.tensor(v) for k, v in xavier_normal_params([F, 32, [128, 128]], seed=0).items()})
             x1 = base[0][2]
-            X1 = vstft.stft(x1, fs=fs, wlen_sec=nfft / fs, hop_percent=0.25).T
-            m1 = vaenmf.MCEM_M1(niter=args.niter, rng="device", precision=args.precision)
-            ts, allocs = [], []
-            for k in range(4):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                m1.init_parameters(X=X1, vae=vae, nmf_rank=args.rank_k, eps=1e-8, device=str(dev))
-                c1 = m1.run()
-                ts.append(time.perf_counter() - t1)
-                allocs.append(int(lib.vaenmf_plan_query(m1._eng._plan, _lib.Q_DEV_ALLOCS)))
-            t1u = sorted(ts[1:])[1]
-            cfg1_gpu = {"workload": "BASELINE config 1: one 4 s utterance (%d frames, F=%d, K=%d), %d EM iterations + Wiener chain through "
-                                    "MCEM_M1.init_parameters + run (rng='device', %s, batch of one, sample store on)" % (X1.shape[0], F, args.rank_k, args.niter, args.precision),
+
+            def one_utt(nfft1, K1, title):
+                F1 = nfft1 // 2 + 1
+                vae = vaenmf.VariationalAutoencoder([F1, 32, [128, 128]])
+                vae.load_state_dict({k: torch.tensor(v) for k, v in xavier_normal_params([F1, 32, [128, 128]], seed=0).items()})
+                X1 = vstft.stft(x1, fs=fs, wlen_sec=nfft1 / fs, hop_percent=0.25).T
+                m1 = vaenmf.MCEM_M1(niter=args.niter, rng="device", precision=args.precision)
+                ts, allocs = [], []
+                for k in range(4):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    m1.init_parameters(X=X1, vae=vae, nmf_rank=K1, eps=1e-8, device=str(dev))
+                    c1 = m1.run()
+                    ts.append(time.perf_counter() - t1)
+                    allocs.append(int(lib.vaenmf_plan_query(m1._eng._plan, _lib.Q_DEV_ALLOCS)))
+                t1u = sorted(ts[1:])[1]
+                return {"workload": "%s: one 4 s utterance (%d frames, F=%d, K=%d), %d EM iterations + Wiener chain through "
+                                    "MCEM_M1.init_parameters + run (rng='device', %s, batch of one, sample store on)" % (title, X1.shape[0], F1, K1, args.niter, args.precision),
                         "value": X1.shape[0] / t1u, "unit": "frames/s", "seconds_per_utterance": t1u,
                         "seconds_all_calls": [round(t, 4) for t in ts], "timing": "median of calls 2-4 (call 1 builds the engine)",
-                        "device_allocations_after_each_call": allocs, "final_cost": float(c1[-1])}
-            del m1
+                        "device_allocations_after_each_call": allocs, "final_cost": float(c1[-1]),
+                        "chain_kernel": {0: "team kernel", 1: "one wavefront per 16 frames", 2: "four wavefronts per 16 frames (wchain4_kernel)"}[
+                            int(lib.vaenmf_plan_query(m1._eng._plan, _lib.Q_CHAIN_KERNEL))]}
+
+            cfg1_gpu = one_utt(nfft, args.rank_k, "BASELINE config 1")
+            if nfft == 512 and args.rank_k == 8:
+                # the shape every script of the reference runs (scripts/evaluate_M1.py:77-92: 64 ms window, rank 10)
+                cfg1_gpu["reference_scripts_shape"] = one_utt(1024, 10, "the reference scripts' own shape")
 
     if rank == 0:
         n_total = int(nutt.item())

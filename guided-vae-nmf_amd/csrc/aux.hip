@@ -102,6 +102,26 @@ __global__ __launch_bounds__(640) void w_update_kernel(const float* __restrict__
   }
 }
 
+// Small batches: wstats_group_kernel (stream.hip) leaves one block of sums per 16-frame GROUP (the groups of utterance u
+// follow those of the utterances before it, ceil(N / 16) each).  A 64-frame tile's partial is rebuilt here from its (up to)
+// four groups in the order wstats_fused_kernel adds its four wavefronts -- ((g0 + g1) + g2) + g3 -- into the tile layout
+// w_update_tiles_kernel reads: the same bits as the tile kernel's.  Block (tile, slot), one thread per bin.
+__global__ void w_combine_groups_kernel(const float* __restrict__ part16, const int32_t* __restrict__ tile_first, const int32_t* __restrict__ frame_off,
+                                        int n_utt, int F, int Fs, int slots, float* __restrict__ part64) {
+  const int T = blockIdx.x, slot = blockIdx.y, f = threadIdx.x;
+  int u = 0;
+  while (u + 1 < n_utt && tile_first[u + 1] <= T) ++u;
+  int g0 = 0;
+  for (int v = 0; v < u; ++v) g0 += (frame_off[v + 1] - frame_off[v] + 15) / 16;
+  const int ng = (frame_off[u + 1] - frame_off[u] + 15) / 16, lt = T - tile_first[u];
+  const int nj = ng - 4 * lt < 4 ? ng - 4 * lt : 4;
+  if (f >= F) return;
+  const float* src = part16 + ((size_t)(g0 + 4 * lt) * slots + slot) * Fs + f;
+  float v = src[0];
+  for (int j = 1; j < nj; ++j) v += src[(size_t)j * slots * Fs];
+  part64[((size_t)T * slots + slot) * Fs + f] = v;
+}
+
 // The same update from the per-tile partial sums of wstats_fused_kernel (stream.hip): part [tile][2 KP][Fs], the tiles of
 // utterance u are tile_first[u] .. tile_first[u+1]-1, added in that order; a tile's block is slot-major: [2 k + stat][Fs].
 template <int KP>
@@ -433,8 +453,13 @@ int vn_launch_w_update(const vaenmf_plan* p, float* W, const float* Ht, hipStrea
   return 0;
 }
 
-int vn_launch_w_update_tiles(const vaenmf_plan* p, float* W, hipStream_t st) {
+int vn_launch_w_update_tiles(const vaenmf_plan* p, float* W, hipStream_t st, bool groups) {
   const int threads = ((p->Fs + 63) / 64) * 64;
+  if (groups) {                                           // group sums -> tile partials (small batches)
+    VN_REQUIRE(p->wpart16, "group partials: rank <= 8 only");
+    hipLaunchKernelGGL(w_combine_groups_kernel, dim3(p->n_t64, 2 * p->Kp), dim3(threads), 0, st, p->wpart16, p->d_t64_first, p->d_frame_off,
+                       p->n_utt, p->cfg.F, p->Fs, 2 * p->Kp, p->wpart64);
+  }
   switch (p->Kp) {
     case 8: hipLaunchKernelGGL((w_update_tiles_kernel<8>), dim3(p->n_utt), dim3(threads), 0, st, p->wpart64, p->d_t64_first, W, p->normW, p->cfg.F, p->Fs, p->cfg.K); break;
     case 16: hipLaunchKernelGGL((w_update_tiles_kernel<16>), dim3(p->n_utt), dim3(threads), 0, st, p->wpart64, p->d_t64_first, W, p->normW, p->cfg.F, p->Fs, p->cfg.K); break;

@@ -68,6 +68,7 @@ struct vaenmf_plan {
   int32_t *d_t64_n0 = nullptr, *d_t64_cnt = nullptr, *d_t64_first = nullptr;      // [n_t64], [n_t64], [n_utt+1]
   int n_t64 = 0;
   float* wpart64 = nullptr;
+  float* wpart16 = nullptr;  // [n_sms][2 Kp][Fs]: per-16-frame-group partials of wstats_group_kernel (small batches, rank <= 8)
   int last_chain_kernel = 0; // VAENMF_Q_CHAIN_KERNEL
   int last_w_fused = 0;      // VAENMF_Q_W_FUSED: 1 when the last stored M-step ran the fused W-statistics kernel
   int Rcap_store;            // samples per frame the store was sized for at vaenmf_bind_batch / vaenmf_sample_store

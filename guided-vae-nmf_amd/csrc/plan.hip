@@ -165,6 +165,7 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   e |= dev_alloc(&p->d_t64_cnt, max_t64);
   e |= dev_alloc(&p->d_t64_first, Uc + 1);
   e |= dev_alloc(&p->wpart64, max_t64 * p->Fs * 2 * p->Kp);
+  if (p->Kp == 8) e |= dev_alloc(&p->wpart16, (size_t)p->n_sms * p->Fs * 2 * p->Kp);
   if (e) { vaenmf_plan_destroy(p); return -2; }
   *out = p;
   return 0;
@@ -175,7 +176,7 @@ extern "C" void vaenmf_plan_destroy(vaenmf_plan* p) {
   void* ptrs[] = {p->w1f, p->w2f, p->w3f, p->b1, p->b2, p->b3, p->w3n, p->w1y, p->d_frame_off, p->d_tile_utt, p->d_tile_n0,
                   p->d_tile_cnt, p->d_frame_utt, p->d_frame_loc, p->d_utt_seed, p->A1, p->P, p->normW, p->wpart, p->cost_frames,
                   p->VsS, p->src, p->w3c, p->b3c, p->d_wt_utt, p->d_wt_n0, p->d_wt_cnt, p->d_t64_n0, p->d_t64_cnt, p->d_t64_first,
-                  p->wpart64};
+                  p->wpart64, p->wpart16};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);

@@ -1230,6 +1230,137 @@ __global__ __launch_bounds__(256, 2) void wstats_fused_kernel(const StreamArgs a
 }
 
 
+// ----------------------------------------------------------------------------
+// The same sums for SMALL batches (no more 16-frame groups than CUs: one utterance through the drop-in classes).  In
+// wstats_fused_kernel a wavefront walks its 16 frames one after the other -- with 8 workgroups on the chip that is 16 frame
+// latencies in a row (44 us per EM iteration for one 4 s utterance).  Here a workgroup owns ONE 16-frame group (a wave tile
+// of the chain) and its four wavefronts compute the statistics of 4 frames each side by side; only the rank-K accumulation
+// -- the part whose ORDER is the result -- stays serial: wavefront 0's frames, barrier, wavefront 1's, ... into one set of
+// LDS accumulators, with the expressions of wstats_fused_kernel.  The group's sums go to part16[group]; w_combine_groups_kernel
+// (aux.hip) adds a tile's four groups in the order wstats_fused_kernel adds its four wavefronts, then the tiles: W, H, g and
+// the cost come out bit-identical to the large-batch path (tested), so an utterance's result still does not depend on the
+// batch it sits in.
+// ----------------------------------------------------------------------------
+template <int KP, int RT>
+__global__ __launch_bounds__(256, 2) void wstats_group_kernel(const StreamArgs a, const int32_t* __restrict__ wt_n0,
+                                                              const int32_t* __restrict__ wt_cnt, int n_groups, float* __restrict__ part16) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  FrameCtx<1, KP, __bf16> fc(a, wlds);
+  float* acc = wlds + (size_t)a.Fs * KP;                  // [slot = 2 k + stat][lane][4 bins], then 2 x 64 floats for the extra bin
+  using RBt = RowBatch<1, __bf16, 1, RT>;
+  const unsigned l4 = (unsigned)fc.lane * 4u;
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int g_n0 = wt_n0[grp], g_cnt = wt_cnt[grp];
+    const int utt = a.frame_utt[g_n0];
+    __syncthreads();                                      // the previous group's readers are done
+    if (utt != fc.wutt) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(a.W + (size_t)utt * a.Fs * KP);
+      for (int e = threadIdx.x; e < a.Fs * KP / 4; e += 256) fc.put_t(e, src[e]);
+      fc.wutt = utt;
+    }
+    for (int sidx = wave; sidx < 2 * KP; sidx += 4) *reinterpret_cast<f32x4*>(acc + sidx * 256 + l4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wave == 0) { acc[2 * KP * 256 + fc.lane] = 0.f; acc[2 * KP * 256 + 64 + fc.lane] = 0.f; }
+    __syncthreads();
+    // ---- phase 1: A1 = sum_r 1/Vx, P = X2 sum_r 1/Vx^2 of this wavefront's (up to) four frames, kept in registers
+    const int n_beg = g_n0 + 4 * wave;
+    const int n_end = n_beg + 4 < g_n0 + g_cnt ? n_beg + 4 : g_n0 + g_cnt;
+    f32x4 A1[4], A2[4];
+    float a1xs[4], pxs[4], hls[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      A1[i] = A2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      a1xs[i] = pxs[i] = hls[i] = 0.f;
+      const int n = n_beg + i;
+      if (n < n_end) {
+        const __bf16* base = reinterpret_cast<const __bf16*>(a.VsS) + (size_t)n * a.Rs * a.Fs;
+        const int sl = RBt::load_slots(fc, a.src + n, 0, RT);
+        const float gn = a.g[n];
+        f32x4 x2[1];
+        float x2x;
+        fc.load_x2(n, x2, x2x);
+        float h[KP];
+#pragma unroll
+        for (int k = 0; k < KP; k += 4) {
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(a.Ht + (size_t)n * KP + k);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) h[k + t] = vn_uniform(hv[t]);
+        }
+        hls[i] = fc.lane < KP ? a.Ht[(size_t)n * KP + (fc.lane < KP ? fc.lane : 0)] : 0.f;      // lane k: H[k, n]
+        fc.set_utt(utt);
+        RBt rb;
+        rb.load_rows(fc, base, sl, 0, RT);
+        f32x4 vb[1], a1, a2;
+        float vbx;
+        fc.noise_var(utt, h, vb, vbx);
+        a1 = a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x2 g2 = {gn, gn};
+        auto row1 = [&](int r) {
+          f32x4 v[1];
+          rb.get(r, v);
+          const f32x2 q0 = rcp2(g2 * v[0].lo + vb[0].lo), q1 = rcp2(g2 * v[0].hi + vb[0].hi);
+          a1.lo += q0; a1.hi += q1;
+          a2.lo = q0 * q0 + a2.lo; a2.hi = q1 * q1 + a2.hi;
+        };
+        rb.for_rows(row1);
+        const float q = fast_rcp(gn * rb.x() + vbx) * rb.xmask(fc);
+        const float a1x = wave_sum(q), a2x = wave_sum(q * q);
+        a2 *= x2[0];                                                        // P = X2 sum_r 1/Vx^2   (mcem.py:107)
+        A1[i] = a1; A2[i] = a2;
+        a1xs[i] = a1x;
+        pxs[i] = a2x * x2x;
+      }
+    }
+    // ---- phase 2: the sums over frames of P H^T and A1 H^T (mcem.py:108-109), frame by frame in the group's order
+    for (int r = 0; r < 4; ++r) {
+      if (wave == r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (n_beg + i < n_end) {
+            float h[KP];
+            rot_h<KP>(hls[i], h);
+            const f32x4 a1 = A1[i], a2 = A2[i];
+#pragma unroll
+            for (int k0 = 0; k0 < KP; k0 += 4) {
+              f32x4 nv[4], dv[4];
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                nv[t] = *reinterpret_cast<const f32x4*>(acc + (2 * (k0 + t)) * 256 + l4);
+                dv[t] = *reinterpret_cast<const f32x4*>(acc + (2 * (k0 + t) + 1) * 256 + l4);
+              }
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                // (explicit fused multiply-adds, the form wstats_fused_kernel's expressions contract to: here the products do not
+                // change from round to round, the compiler hoists them out of the round loop and would add them unfused)
+                const f32x4 hh = {h[k0 + t], h[k0 + t], h[k0 + t], h[k0 + t]};
+                *reinterpret_cast<f32x4*>(acc + (2 * (k0 + t)) * 256 + l4) = __builtin_elementwise_fma(a2, hh, nv[t]);
+                *reinterpret_cast<f32x4*>(acc + (2 * (k0 + t) + 1) * 256 + l4) = __builtin_elementwise_fma(a1, hh, dv[t]);
+              }
+            }
+            const float hl = hls[i];
+            float numx = acc[2 * KP * 256 + fc.lane], denx = acc[2 * KP * 256 + 64 + fc.lane];
+            numx = __builtin_fmaf(pxs[i], hl, numx);
+            denx = __builtin_fmaf(a1xs[i], hl, denx);
+            acc[2 * KP * 256 + fc.lane] = numx;
+            acc[2 * KP * 256 + 64 + fc.lane] = denx;
+          }
+      }
+      __syncthreads();
+    }
+    // ---- the group's sums, slot-major [2 k + stat][Fs] like a tile's partial
+    float* dst = part16 + (size_t)grp * 2 * KP * a.Fs;
+    for (int sidx = wave; sidx < 2 * KP; sidx += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(acc + sidx * 256 + l4);
+      if (fc.cv[0]) *reinterpret_cast<f32x4*>(dst + (size_t)sidx * a.Fs + fc.f0[0]) = v;
+    }
+    if (wave == 0 && fc.has_x && fc.lane < KP) {
+      dst[(size_t)(2 * fc.lane) * a.Fs + a.F - 1] = acc[2 * KP * 256 + fc.lane];
+      dst[(size_t)(2 * fc.lane + 1) * a.Fs + a.F - 1] = acc[2 * KP * 256 + 64 + fc.lane];
+    }
+  }
+}
+
+
 StreamArgs base_args(const vaenmf_plan* p) {
   StreamArgs a = {};
   a.VsS = p->VsS; a.src = p->src; a.frame_utt = p->d_frame_utt; a.Vb = p->Vb_ext;
@@ -1348,7 +1479,7 @@ int check_store(const vaenmf_plan* p) {
 
 // aux.hip
 int vn_launch_w_update(const vaenmf_plan* p, float* W, const float* Ht, hipStream_t st);
-int vn_launch_w_update_tiles(const vaenmf_plan* p, float* W, hipStream_t st);
+int vn_launch_w_update_tiles(const vaenmf_plan* p, float* W, hipStream_t st, bool groups);
 
 namespace {
 // W statistics + the W update's sums in one kernel: the bench shapes of wstats_rot (bf16 rows, one 256-bin chunk, rank <= 8,
@@ -1357,6 +1488,20 @@ bool w_fused_ok(const vaenmf_plan* p, const StreamArgs& a) {
   if (!(VN_ROT && !a.store_f32 && p->Kp == 8 && (p->Fm + 255) / 256 == 1 && (a.R == 30 || a.R == 10) && !a.gains_only)) return false;
   const char* e = getenv("VAENMF_WFUSED");              // (read per call: tests switch it inside one process)
   return !(e && e[0] == '0');
+}
+// small batches: one workgroup per 16-frame group (VAENMF_WGROUP=0 keeps the tile kernel: tests)
+bool w_group_ok(const vaenmf_plan* p) {
+  if (!(p->wpart16 && p->n_wtiles <= p->n_sms)) return false;
+  const char* e = getenv("VAENMF_WGROUP");
+  return !(e && e[0] == '0');
+}
+int launch_w_group(const vaenmf_plan* p, StreamArgs a, hipStream_t st) {
+  const size_t lds = ((size_t)a.Fs * 8 + (size_t)wf_acc_floats<8>()) * sizeof(float);
+  const int grid = p->n_wtiles;
+  if (a.R == 30) hipLaunchKernelGGL((wstats_group_kernel<8, 30>), dim3(grid), dim3(256), lds, st, a, p->d_wt_n0, p->d_wt_cnt, p->n_wtiles, p->wpart16);
+  else hipLaunchKernelGGL((wstats_group_kernel<8, 10>), dim3(grid), dim3(256), lds, st, a, p->d_wt_n0, p->d_wt_cnt, p->n_wtiles, p->wpart16);
+  VN_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 int launch_w_fused(const vaenmf_plan* p, StreamArgs a, hipStream_t st) {
   a.t64_n0 = p->d_t64_n0; a.t64_cnt = p->d_t64_cnt; a.n_t64 = p->n_t64; a.wpart64 = p->wpart64;
@@ -1392,9 +1537,13 @@ extern "C" int vaenmf_m_step_stored(vaenmf_plan* p, const float* X2, float* W, f
     return launch_stream<SK_HG>(p, a, st);
   }
   p->last_w_fused = w_fused_ok(p, a) ? 1 : 0;
-  if (p->last_w_fused) {
+  if (p->last_w_fused && w_group_ok(p)) {
+    p->last_w_fused = 2;
+    { ProfScope ps(p, VN_K_WSTATS, st); if (int e = launch_w_group(p, a, st)) return e; }
+    { ProfScope ps(p, VN_K_WUPDATE, st); if (int e = vn_launch_w_update_tiles(p, W, st, true)) return e; }
+  } else if (p->last_w_fused) {
     { ProfScope ps(p, VN_K_WSTATS, st); if (int e = launch_w_fused(p, a, st)) return e; }
-    { ProfScope ps(p, VN_K_WUPDATE, st); if (int e = vn_launch_w_update_tiles(p, W, st)) return e; }
+    { ProfScope ps(p, VN_K_WUPDATE, st); if (int e = vn_launch_w_update_tiles(p, W, st, false)) return e; }
   } else {
     { ProfScope ps(p, VN_K_WSTATS, st); if (int e = launch_stream<SK_WSTATS>(p, a, st)) return e; }
     { ProfScope ps(p, VN_K_WUPDATE, st); if (int e = vn_launch_w_update(p, W, Ht, st)) return e; }

@@ -55,7 +55,8 @@ enum { VAENMF_Q_FS = 0, VAENMF_Q_KP = 1, VAENMF_Q_TILES = 2, VAENMF_Q_NT = 3, VA
        VAENMF_Q_MSTEP_PATH = 5,  /* M-step path of the last vaenmf_em_run: 1 = streaming the sample store, 2 = decoding */
        VAENMF_Q_WTILES = 6,      /* 16-frame wave tiles of the bound batch */
        VAENMF_Q_EM_GRAPH = 7,    /* 1 when the last vaenmf_em_run was launched as a captured HIP graph, 0 when launch by launch */
-       VAENMF_Q_W_FUSED = 9,     /* 1 when the last stored M-step ran the W statistics fused with the W update's sums over frames */
+       VAENMF_Q_W_FUSED = 9,     /* 1 when the last stored M-step ran the W statistics fused with the W update's sums over frames
+                                    (2: per 16-frame group, the small-batch form; the same bits) */
        VAENMF_Q_CHAIN_KERNEL = 10, /* kernel of the last MH chain: 0 = team kernel (64-bit addresses), 1 = one wavefront per 16 frames,
                                       2 = four wavefronts per 16 frames (bench shape, batches of at most one wave tile per CU) */
        VAENMF_Q_DEV_ALLOCS = 8 };/* device allocations the library has made in this process so far (any plan): a caller that

@@ -1149,6 +1149,7 @@ def test_fused_w_statistics_equal_the_two_kernel_path(R, counts):
 
     def run(fused):
         os.environ["VAENMF_WFUSED"] = "1" if fused else "0"
+        os.environ["VAENMF_WGROUP"] = "0"                  # (this test is about the TILE kernel; small batches would take the group kernel)
         try:
             eng = make_engine(params, F, K, counts, Rcap=R, precision="bf16", seeds=list(range(len(counts))))
             eng.set_spectrogram(Xs)
@@ -1161,6 +1162,7 @@ def test_fused_w_statistics_equal_the_two_kernel_path(R, counts):
             return [t.cpu().numpy().copy() for t in (eng.W, eng.Ht, eng.g, c)]
         finally:
             os.environ.pop("VAENMF_WFUSED", None)
+            os.environ.pop("VAENMF_WGROUP", None)
 
     a, b, a2 = run(True), run(False), run(True)
     for x, y, name in zip(a, b, ("W", "Ht", "g", "cost")):
@@ -1505,3 +1507,44 @@ def test_four_wavefront_chain_equals_the_wave_chain_bit_for_bit(F, K, model, rng
     assert np.abs(a[1] - Z0[:, None, :]).max() > 0.05            # the chains moved
     for x, yv, name in zip(a, b, names):
         assert np.array_equal(x, yv), name
+
+
+@pytest.mark.parametrize("R,counts", [(30, [33, 17, 5, 70, 64]), (10, [129, 1, 16]), (30, [501])])
+def test_group_w_statistics_equal_the_tile_kernel_bit_for_bit(R, counts):
+    """Small batches run wstats_group_kernel: one workgroup per 16-frame group, the four wavefronts compute the statistics of
+    4 frames each side by side, the rank-K sums over frames are accumulated in the group's frame order, and the W update
+    rebuilds every 64-frame tile from its groups in the order wstats_fused_kernel adds its four wavefronts (mcem.py:107-110).
+    W, normalisation and -- through the H/g kernel -- H, g and the cost are bit-identical to the tile kernel's: ragged
+    utterances with full tiles, tiles of 1, 2, 3 groups, groups of 1 / 5 / 6 frames."""
+    need_gpu()
+    from vaenmf import _lib
+    F, K = 257, 8
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=5, bias_std=0.05)
+    g = np.random.default_rng(R + len(counts))
+    Xs = [((g.standard_normal((n, F)) + 1j * g.standard_normal((n, F))) * (0.5 + 3 * np.exp(-np.arange(F) / 60.0))).astype(np.complex64) for n in counts]
+    W0 = [np.maximum(g.random((F, K)), 1e-8).astype(np.float32) for _ in counts]
+    H0 = [np.maximum(g.random((K, n)), 1e-8).astype(np.float32) for n in counts]
+    gains = (0.5 + g.random(sum(counts))).astype(np.float32)
+
+    def run(group):
+        os.environ["VAENMF_WGROUP"] = "1" if group else "0"
+        try:
+            eng = make_engine(params, F, K, counts, Rcap=R, precision="bf16", seeds=list(range(len(counts))))
+            eng.set_spectrogram(Xs)
+            eng.init_nmf(W0, H0)
+            eng.g.copy_(torch.from_numpy(gains))
+            eng.sample_store(True)
+            out = []
+            for it in range(2):                                      # the second iteration starts from the first one's W, H, g
+                eng.mh_chain(R, 3, 0.01, call=it)
+                c = eng.m_step_stored().clone()
+                assert _lib.lib().vaenmf_plan_query(eng._plan, _lib.Q_W_FUSED) == (2 if group else 1)
+                out += [t.cpu().numpy().copy() for t in (eng.W, eng.Ht, eng.g, c)]
+            return out
+        finally:
+            os.environ.pop("VAENMF_WGROUP", None)
+
+    a, b = run(True), run(False)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), ("W", "Ht", "g", "cost")[i % 4] + " of iteration %d" % (i // 4)
+    assert np.all(np.isfinite(a[0])) and float(np.abs(a[4] - a[0]).max()) > 0
