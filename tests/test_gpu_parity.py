@@ -1449,9 +1449,12 @@ def test_tiny_and_ragged_utterances_against_the_oracle(counts, prec):
         assert nrm_err(sh, o["WFs"] * o["o"].X) < 2e-3
 
 
-@pytest.mark.parametrize("F,K,model,rng", [(257, 8, "M1", "device"), (257, 8, "M2", "device"), (257, 8, "M1", "replay"),
-                                           (513, 10, "M1", "device"), (513, 10, "M2", "device"), (513, 32, "M1", "replay")])
-def test_four_wavefront_chain_equals_the_wave_chain_bit_for_bit(F, K, model, rng):
+@pytest.mark.parametrize("F,K,model,rng,zdim,hdim", [(257, 8, "M1", "device", 32, [128, 128]), (257, 8, "M2", "device", 32, [128, 128]),
+                                                     (257, 8, "M1", "replay", 32, [128, 128]), (513, 10, "M1", "device", 32, [128, 128]),
+                                                     (513, 10, "M2", "device", 32, [128, 128]), (513, 32, "M1", "replay", 32, [128, 128]),
+                                                     # decoder shapes of section 3.8: one hidden layer (two barriers per evaluation), 16 latents
+                                                     (257, 8, "M1", "device", 16, [128]), (513, 10, "M2", "replay", 16, [128])])
+def test_four_wavefront_chain_equals_the_wave_chain_bit_for_bit(F, K, model, rng, zdim, hdim):
     """Small batches of the bench shape (at most one 16-frame wave tile per CU: one utterance through the drop-in classes)
     run wchain4_kernel -- four wavefronts per tile, each owning two of the output layer's eight bin-tile pairs, the pair
     energies exchanged through LDS and added in the one-wavefront kernel's order.  Same proposals, same log-acceptances,
@@ -1464,15 +1467,17 @@ def test_four_wavefront_chain_equals_the_wave_chain_bit_for_bit(F, K, model, rng
     counts = [33, 17, 5]
     NT = sum(counts)
     ydim = F if model == "M2" else 0
-    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=5, y_dim=ydim, bias_std=0.05)
+    params = orc.xavier_normal_params([F, zdim, hdim], seed=5, y_dim=ydim, bias_std=0.05)
     g = np.random.default_rng(7)
     Xs = [((g.standard_normal((n, F)) + 1j * g.standard_normal((n, F))) * (0.5 + 3 * np.exp(-np.arange(F) / 60.0))).astype(np.complex64) for n in counts]
     W0 = [np.maximum(g.random((F, K)), 1e-8).astype(np.float32) for _ in counts]
     H0 = [np.maximum(g.random((K, n)), 1e-8).astype(np.float32) for n in counts]
     gains = (0.5 + g.random(NT)).astype(np.float32)
     Z0 = (0.5 * g.standard_normal((NT, 32))).astype(np.float32)
+    Z0[:, zdim:] = 0.0
     y = (g.random((NT, F)) > 0.5).astype(np.float32)
     eps = g.standard_normal((R + BI, NT, 32)).astype(np.float32)
+    eps[:, :, zdim:] = 0.0
     u = g.random((R + BI, NT)).astype(np.float32)
 
     def run(four):
