@@ -40,6 +40,9 @@ __device__ long long g_wc_stamp[32];
 #ifndef VN_PACKED
 #define VN_PACKED 1
 #endif
+#ifndef VN_ST_AUX
+#define VN_ST_AUX 0      // cache policy of the sample-variance row stores (2 = nt)
+#endif
 #ifndef VN_PFL
 #define VN_PFL 3      // bf16x3 mode, F > 80: tiles of W3-lo fragments (streamed from L2, ~1 us away) in flight ahead of their MFMAs -- with one
                       // tile the single wavefront of a SIMD sat out the L2 latency once per bin tile
@@ -500,14 +503,14 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
 #endif
                   if (DOST) {
                     if (SPLIT) {
-                      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), vrs, voff + 16u * q + 64u * t, 0, 0);
+                      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ev), vrs, voff + 16u * q + 64u * t, 0, VN_ST_AUX);
                     } else {
                       const unsigned p0 = pk2(ev[0], ev[1]), p1 = pk2(ev[2], ev[3]);
                       if (t < Tm) {
                         if ((t & 1) == 0) { pk_even0 = p0; pk_even1 = p1; }
-                        else __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk_even0, pk_even1, p0, p1}, vrs, voff + 16u * q + 64u * (t >> 1), 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk_even0, pk_even1, p0, p1}, vrs, voff + 16u * q + 64u * (t >> 1), 0, VN_ST_AUX);
                       } else {
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{p0, p1}, vrs, voff + 8u * q + 32u * t, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{p0, p1}, vrs, voff + 8u * q + 32u * t, 0, VN_ST_AUX);
                       }
                     }
                   }
@@ -838,9 +841,9 @@ __global__ __launch_bounds__(256, 1) void wchain4_kernel(const WcArgs a) {
           const unsigned t = (unsigned)tile_of(i);
           if (i < 2 * PPW) {
             if ((i & 1) == 0) { pk_even0 = p0; pk_even1 = p1; }
-            else __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk_even0, pk_even1, p0, p1}, vrs, voff + 16u * q + 64u * (t >> 1), 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk_even0, pk_even1, p0, p1}, vrs, voff + 16u * q + 64u * (t >> 1), 0, VN_ST_AUX);
           } else {
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{p0, p1}, vrs, voff + 8u * q + 32u * t, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{p0, p1}, vrs, voff + 8u * q + 32u * t, 0, VN_ST_AUX);
           }
         }
         if ((i & 1) == 1 || i == 2 * PPW) {     // fp32 over a pair's two tiles (the odd last tile alone), as wchain_kernel

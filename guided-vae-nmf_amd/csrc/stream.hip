@@ -58,6 +58,17 @@
 #ifndef VN_HG_EXACT2
 #define VN_HG_EXACT2 1     // exact-count H/g kernel for two-chunk rows at rank <= 16 (F = 513, K = 10: 0.2625 -> 0.250 ms)
 #endif
+// Non-temporal loads for the sample-variance rows (each row is read once per kernel and the store, 0.54 GB, passes every
+// cache): measured on one box, alternating builds -- W statistics 0.131-0.137 -> 0.121-0.124 ms, step 71.9 -> 70.5 ms (the H/g
+// kernel, VALU-bound, does not move).  What the rows compete with is the chain's own write-back: with non-temporal STORES in
+// the chain the W statistics drop to 0.099 ms (4.9 TB/s), but the chain pays 0.39 -> 0.53 ms for them (sc1 stores: 0.46), so
+// the stores stay cached.
+#ifndef VN_ROW_AUX
+#define VN_ROW_AUX 2     // cache policy of the row loads of wstats_rot / wstats_fused (buffer loads: 2 = nt)
+#endif
+#ifndef VN_ROW_NT
+#define VN_ROW_NT 1      // non-temporal row loads in the RowBatch kernels (wstats_stream, wstats_group, hg_stream, wf_stream)
+#endif
 #ifndef VN_STREAM2
 #define VN_STREAM2 1      // frame-pipelined W-statistics kernel (dev builds: 0 = the batch-at-a-time form)
 #endif
@@ -340,7 +351,7 @@ struct RowBatch {
         const ST* row = base + (size_t)__builtin_amdgcn_readlane(sl, r) * fc.a.Fs;
 #endif
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) raw[r][c] = *reinterpret_cast<const raw_t*>(row + fc.fo[c]);
+        for (int c = 0; c < NCH; ++c) raw[r][c] = VN_ROW_NT ? __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(row + fc.fo[c])) : *reinterpret_cast<const raw_t*>(row + fc.fo[c]);
       }
     // extra bin, raw bits (x() converts at the use: a conversion here would wait for every load above)
     if (fc.has_x) {
@@ -1000,7 +1011,7 @@ struct RotCtx {
     const unsigned so = (unsigned)n * frameb + (unsigned)__builtin_amdgcn_readlane(sl, r) * rowb;
     unsigned vo = vbase;
     asm volatile("" : "+v"(vo) : "v"(after));
-    raw[S][r] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(vrs, vo, so, 0));
+    raw[S][r] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(vrs, vo, so, VN_ROW_AUX));
   }
   template <int S>
   __device__ __forceinline__ void req_x(int n, int sl, bool on) {
