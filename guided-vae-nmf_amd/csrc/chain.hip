@@ -217,7 +217,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
   auto tile_on3 = [&](int n, int t) { return n != MAXT || EXACT || t < NT3; };      // (hidden layers: every tile)
 
   __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(a.VsS, 0, STORE ? (int)a.VsS_bytes : 0, 0x00020000);
-  __amdgpu_buffer_rsrc_t zs_rs = __builtin_amdgcn_make_buffer_rsrc(a.Zs, 0, (int)((unsigned)a.NT * (unsigned)a.Rcap * LAT * 4u), 0x00020000);
+  __amdgpu_buffer_rsrc_t zs_rs = __builtin_amdgcn_make_buffer_rsrc(a.Zs, 0, a.Zs ? (int)((unsigned)a.NT * (unsigned)a.Rcap * LAT * 4u) : 0, 0x00020000);   // (no Zs: the sample stores fall outside the resource and are dropped)
   __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(a.src, 0, STORE ? (int)((unsigned)a.NT * (unsigned)a.Rs * 4u) : 0, 0x00020000);
   __amdgpu_buffer_rsrc_t acc_rs = __builtin_amdgcn_make_buffer_rsrc(a.acc_out, 0, a.acc_out ? (int)((unsigned)a.NT * (unsigned)S * 4u) : 0, 0x00020000);
   __amdgpu_buffer_rsrc_t eps_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.eps), 0, a.eps ? (int)((unsigned)a.NT * (unsigned)S * LAT * 4u) : 0, 0x00020000);
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256, 1) void wchain4_kernel(const WcArgs a) {
   }
 
   __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(a.VsS, 0, STORE ? (int)a.VsS_bytes : 0, 0x00020000);
-  __amdgpu_buffer_rsrc_t zs_rs = __builtin_amdgcn_make_buffer_rsrc(a.Zs, 0, (int)((unsigned)a.NT * (unsigned)a.Rcap * LAT * 4u), 0x00020000);
+  __amdgpu_buffer_rsrc_t zs_rs = __builtin_amdgcn_make_buffer_rsrc(a.Zs, 0, a.Zs ? (int)((unsigned)a.NT * (unsigned)a.Rcap * LAT * 4u) : 0, 0x00020000);   // (no Zs: the sample stores fall outside the resource and are dropped)
   __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(a.src, 0, STORE ? (int)((unsigned)a.NT * (unsigned)a.Rs * 4u) : 0, 0x00020000);
   __amdgpu_buffer_rsrc_t acc_rs = __builtin_amdgcn_make_buffer_rsrc(a.acc_out, 0, a.acc_out ? (int)((unsigned)a.NT * (unsigned)S * 4u) : 0, 0x00020000);
   __amdgpu_buffer_rsrc_t eps_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.eps), 0, a.eps ? (int)((unsigned)a.NT * (unsigned)S * LAT * 4u) : 0, 0x00020000);

@@ -1467,6 +1467,7 @@ extern "C" int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, 
     if (p->store_on) { p->store_R = nsamples; p->store_Rs = nsamples + 1; }
     return 0;
   }
+  VN_REQUIRE(Zs != nullptr, "vaenmf_mh_chain: Zs may be NULL only where the wave-private chain kernels run (vaenmf_wchain_addressable)");
   ProfScope ps(p, VN_K_CHAIN, st);
   int lrc = 0;
   switch (p->geom) {
@@ -1597,10 +1598,16 @@ static int em_run_body(vaenmf_plan* p, const float* X2, float* W, float* Ht, flo
   // the per-frame cost sums of VN_COST_CHUNK iterations are kept (one row of the plan's cost buffer each) and reduced to
   // cost[u][it] by ONE launch per chunk instead of one per iteration
   const size_t cstride = (size_t)p->cfg.max_frames;
+  // With the sample-variance store on, the M-step never looks at the E-step's latent samples: the wave-private chain kernels
+  // then do not record them (Zs = NULL: 123 MB of writes per launch at the bench shape that nothing reads); the Wiener chain
+  // below records its own, which is what Zs holds after the reference's run() too (mcem.py:173, :477-482).
+  const char* keep = getenv("VAENMF_KEEP_ZS");          // dev / test switch: 1 = record the E-step samples anyway
+  float* Zs_e = (stored && !(keep && keep[0] == '1') && vn_wchain_supported(p) &&
+                 vaenmf_wchain_addressable(p->NT, Rcap, nsE + biE, p->Fs, p->Kp, p->n_utt, 0)) ? nullptr : Zs;
   for (int it = 0; it < niter; ++it) {                  // EM.run, mcem.py:159-165
     rng.call = (uint32_t)it;
     double* cf = p->cost_frames + (size_t)(it % VN_COST_CHUNK) * cstride;
-    if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, 1, B1, Zs, Rcap, nsE, biE, var_rw, &rng, nullptr, stream)) return e;
+    if (int e = vaenmf_mh_chain(p, X2, W, Ht, g, Z, 1, B1, Zs_e, Rcap, nsE, biE, var_rw, &rng, nullptr, stream)) return e;
     if (int e = stored ? vaenmf_m_step_stored(p, X2, W, Ht, g, cf, stream)
                        : vaenmf_m_step(p, X2, W, Ht, g, Zs, Rcap, nsE, B1, cf, stream)) return e;
     if (cost && ((it + 1) % VN_COST_CHUNK == 0 || it + 1 == niter)) {

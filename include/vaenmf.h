@@ -131,7 +131,10 @@ int vaenmf_set_noise_psd(vaenmf_plan* p, const float* Vb);
  * nsamples+burnin random-walk steps per frame, samples after burn-in to Zs[:, 0..nsamples-1, :].
  * update_Z != 0: Z is overwritten with the last draw, as E_step does (mcem.py:466);
  * update_Z == 0: Z is only read, as compute_WF does (mcem.py:477-478).  acc_out (DEV
- * [S][NT], may be NULL) receives the log-acceptance of every step (mcem.py:415-417). */
+ * [S][NT], may be NULL) receives the log-acceptance of every step (mcem.py:415-417).
+ * Zs may be NULL where the wave-private chain kernels run (vaenmf_wchain_addressable; every shape but F > 528 and bf16x3 with
+ * F > 272): the samples are then not recorded -- with the sample-variance store on nothing reads them (vaenmf_em_run does
+ * this for its E-steps). */
 int vaenmf_mh_chain(vaenmf_plan* p, const float* X2, const float* W, const float* Ht, const float* g,
                     float* Z, int32_t update_Z, const float* B1, float* Zs, int32_t Rcap,
                     int32_t nsamples, int32_t burnin, float var_rw,
