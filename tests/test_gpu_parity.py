@@ -1553,3 +1553,41 @@ def test_group_w_statistics_equal_the_tile_kernel_bit_for_bit(R, counts):
     for i, (x, y) in enumerate(zip(a, b)):
         assert np.array_equal(x, y), ("W", "Ht", "g", "cost")[i % 4] + " of iteration %d" % (i // 4)
     assert np.all(np.isfinite(a[0])) and float(np.abs(a[4] - a[0]).max()) > 0
+
+
+@pytest.mark.parametrize("nfft,K,NU", [(512, 8, 24), (1024, 10, 48)])
+def test_small_batch_kernels_give_the_large_batch_result(nfft, K, NU):
+    """A batch with no more 16-frame wave tiles than CUs runs wchain4_kernel and wstats_group_kernel, a larger one
+    wchain_kernel and wstats_fused_kernel.  The same utterance alone (small-batch kernels) and inside a batch of 24 / 48
+    (large-batch kernels; checked through the plan queries): enhanced signals and cost bit for bit -- through the whole
+    fused pipeline (STFT, device NMF initialisation, graph-replayed EM loop, Wiener filter, iSTFT)."""
+    need_gpu()
+    from vaenmf import _lib
+    from vaenmf.pipeline import Reconstructor
+    dev = torch.device("cuda:0")
+    n_sms = torch.cuda.get_device_properties(0).multi_processor_count
+    T = [20000 + 997 * (i % 11) for i in range(NU)]
+    sig = [orc.synth_utterance(u, t) for u, t in enumerate(T)]
+    F = nfft // 2 + 1
+    params = orc.xavier_normal_params([F, 32, [128, 128]], seed=0)
+    rec = Reconstructor(params, F, K, niter=3, fs=16000, wlen_sec=nfft / 16000, precision="bf16", device=dev, max_frames=NU * 260, max_utts=NU)
+
+    def run(idx):
+        wav = torch.from_numpy(np.concatenate([sig[i][2] for i in idx]).astype(np.float32)).to(dev)
+        s, n, c = rec.enhance(wav, [T[i] for i in idx], seeds=[100 + i for i in idx], init_seed=0)
+        off = np.concatenate([[0], np.cumsum([T[i] for i in idx])])
+        s = s.cpu().numpy()
+        kern = _lib.lib().vaenmf_plan_query(rec.eng._plan, _lib.Q_CHAIN_KERNEL)
+        tiles = _lib.lib().vaenmf_plan_query(rec.eng._plan, _lib.Q_WTILES)
+        return {i: (s[off[k]:off[k + 1]], c[k].cpu().numpy()) for k, i in enumerate(idx)}, kern, tiles
+
+    big, kb, tb = run(list(range(NU)))
+    for i in (5, 17):
+        one, k1, t1 = run([i])
+        assert t1 <= n_sms and k1 == 2, (t1, k1)
+        for x, y in zip(big[i], one[i]):
+            assert np.array_equal(x, y), i
+    if tb > n_sms:
+        assert kb == 1, kb
+    else:
+        pytest.skip("this GPU has %d CUs: the %d-utterance batch (%d wave tiles) still counts as small" % (n_sms, NU, tb))
