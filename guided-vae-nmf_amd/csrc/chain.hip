@@ -44,8 +44,12 @@ __device__ long long g_wc_stamp[32];
 #define VN_ST_AUX 0      // cache policy of the sample-variance row stores (2 = nt)
 #endif
 #ifndef VN_PFL
-#define VN_PFL 3      // bf16x3 mode, F > 80: tiles of W3-lo fragments (streamed from L2, ~1 us away) in flight ahead of their MFMAs -- with one
-                      // tile the single wavefront of a SIMD sat out the L2 latency once per bin tile
+#define VN_PFL 2      // bf16x3 mode, F > 80: tiles of W3-lo fragments (streamed from L2, ~1 us away) in flight ahead of their MFMAs -- with one
+                      // tile the single wavefront of a SIMD sat out the L2 latency once per bin tile (1.00 -> 0.89 ms per launch)
+#endif
+#ifndef VN_PFL_HOIST
+#define VN_PFL_HOIST 2     // of those, tiles requested at the top of the evaluation, two layers before their use (registers live through the
+                           // hidden layers: 2 + 2 fits the 512 registers, 3 + 1 spills; 132.5 -> 131.8 ms per bf16x3 step)
 #endif
 #ifndef VN_TPM
 #define VN_TPM 2      // transcendentals scheduled right behind each MFMA (a packed instruction waits for a matrix instruction in flight); 0: mixed with the other VALU work
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
       // wavefront covers its own LDS and MFMA latencies with epilogue work.
       //   NKS k-steps; frag(t, s, hi, lo) loads; bias(t); bop(s, hi, lo) the input fragments; epi(t, acc)
       //   frag_lo(t, s, lo): the lo fragments (bf16x3 mode), PFL tiles ahead
-      auto run_layer = [&](auto nks_c, auto ntiles_c, auto pfl_c, auto frag, auto frag_lo, auto bias, auto bop, auto epi) {
+      auto run_layer = [&](auto nks_c, auto ntiles_c, auto pfl_c, auto frag, auto frag_lo, auto frag_lo_pro, auto bias, auto bop, auto epi) {
         constexpr int NKS = decltype(nks_c)::value, N = decltype(ntiles_c)::value;
         // VN_PF tiles of weight fragments (and bias) in flight ahead of the MFMAs that use them
         constexpr int PF = VN_PF, NB = PF + 1;
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
         for (int p = 0; p < PFL; ++p)
           if (p < N) {
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) frag_lo(p, s, wl[p % NBL][s]);
+            for (int s = 0; s < NKS; ++s) frag_lo_pro(p, s, wl[p % NBL][s]);
           }
 #pragma unroll
         for (int p = 0; p < PF; ++p)
@@ -415,6 +419,16 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
           if (VN_TPR <= 1 || (t % VN_TPR) == VN_TPR - 1 || t == N) VN_SB;      // VN_TPR tiles per scheduling region
         }
       };
+      // bf16x3 mode, W3-lo streamed from L2: the first NHOIST tiles' lo fragments are requested here, two layers before their
+      // use (the single wavefront of a SIMD otherwise sits out one L2 round trip per evaluation at the head of the output layer)
+      constexpr int NHOIST = (SPLIT && !LOL && !M2) ? VN_PFL_HOIST : 0;      // (M2 keeps its 32 bias registers instead)
+      bf16x8 lo_pre[NHOIST > 0 ? NHOIST : 1][NK];
+      if (NHOIST > 0) {
+#pragma unroll
+        for (int t = 0; t < NHOIST; ++t)
+#pragma unroll
+          for (int s = 0; s < NK; ++s) lo_pre[t][s] = *reinterpret_cast<const bf16x8*>(w3g + (size_t)((t * NK + s) * 2 + 1) * 1024 + l16);
+      }
       bf16x8 gfr[GT > 0 ? GT : 1][NK];                 // hi fragments of the bin tiles that live in global memory (L2)
       if (GT > 0) {
 #pragma unroll
@@ -433,6 +447,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
         }
         run_layer(std::integral_constant<int, 1>{}, std::integral_constant<int, NTH>{}, std::integral_constant<int, VN_PF>{},
                   [&](int t, int, bf16x8& hi) { hi = *reinterpret_cast<const bf16x8*>(smem + L::W1 + t * PARTS * 1024 + l16); },
+                  [&](int t, int, bf16x8& lo) { lo = *reinterpret_cast<const bf16x8*>(smem + L::W1 + t * PARTS * 1024 + (SPLIT ? 1024 : 0) + l16); },
                   [&](int t, int, bf16x8& lo) { lo = *reinterpret_cast<const bf16x8*>(smem + L::W1 + t * PARTS * 1024 + (SPLIT ? 1024 : 0) + l16); },
                   [&](int t) {
                     if (B1L) {
@@ -453,6 +468,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
       run_layer(std::integral_constant<int, NK>{}, std::integral_constant<int, NTH>{}, std::integral_constant<int, VN_PF>{},
                 [&](int t, int s, bf16x8& hi) { hi = *reinterpret_cast<const bf16x8*>(smem + L::W2 + (t * NK + s) * PARTS * 1024 + l16); },
                 [&](int t, int s, bf16x8& lo) { lo = *reinterpret_cast<const bf16x8*>(smem + L::W2 + (t * NK + s) * PARTS * 1024 + (SPLIT ? 1024 : 0) + l16); },
+                [&](int t, int s, bf16x8& lo) { lo = *reinterpret_cast<const bf16x8*>(smem + L::W2 + (t * NK + s) * PARTS * 1024 + (SPLIT ? 1024 : 0) + l16); },
                 [&](int t) { return *reinterpret_cast<const f32x4*>(b2l + 16 * t + 4 * q); },
                 [&](int s, bf16x8& hi, bf16x8& lo) { hi = __builtin_bit_cast(bf16x8, ch[s]); lo = SPLIT ? __builtin_bit_cast(bf16x8, cl[s]) : hi; },
                 [&](int t, const f32x4 acc) { put(bh, bl, t, tanh4(acc)); });
@@ -471,6 +487,11 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void wchain_kernel(const W
                 },
                 [&](int t, int s, bf16x8& lo) {
                   if (LOL) lo = *reinterpret_cast<const bf16x8*>(w3lo_lds + (t * NK + s) * 1024 + l16);
+                  else lo = *reinterpret_cast<const bf16x8*>(w3g + (size_t)((t * NK + s) * 2 + 1) * 1024 + l16);
+                },
+                [&](int t, int s, bf16x8& lo) {           // the first tiles' lo fragments: requested at the top of the evaluation (VN_PFL_HOIST)
+                  if (LOL) lo = *reinterpret_cast<const bf16x8*>(w3lo_lds + (t * NK + s) * 1024 + l16);
+                  else if (t < NHOIST) lo = lo_pre[t < NHOIST ? t : 0][s];
                   else lo = *reinterpret_cast<const bf16x8*>(w3g + (size_t)((t * NK + s) * 2 + 1) * 1024 + l16);
                 },
                 [&](int t) { return *reinterpret_cast<const f32x4*>(b3l + 16 * t + 4 * q); },
