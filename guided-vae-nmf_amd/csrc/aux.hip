@@ -106,17 +106,12 @@ __global__ __launch_bounds__(640) void w_update_kernel(const float* __restrict__
 // follow those of the utterances before it, ceil(N / 16) each).  A 64-frame tile's partial is rebuilt here from its (up to)
 // four groups in the order wstats_fused_kernel adds its four wavefronts -- ((g0 + g1) + g2) + g3 -- into the tile layout
 // w_update_tiles_kernel reads: the same bits as the tile kernel's.  Block (tile, slot), one thread per bin.
-__global__ void w_combine_groups_kernel(const float* __restrict__ part16, const int32_t* __restrict__ tile_first, const int32_t* __restrict__ frame_off,
-                                        int n_utt, int F, int Fs, int slots, float* __restrict__ part64) {
+__global__ void w_combine_groups_kernel(const float* __restrict__ part16, const int32_t* __restrict__ tile_g0, const int32_t* __restrict__ tile_cnt,
+                                        int F, int Fs, int slots, float* __restrict__ part64) {
   const int T = blockIdx.x, slot = blockIdx.y, f = threadIdx.x;
-  int u = 0;
-  while (u + 1 < n_utt && tile_first[u + 1] <= T) ++u;
-  int g0 = 0;
-  for (int v = 0; v < u; ++v) g0 += (frame_off[v + 1] - frame_off[v] + 15) / 16;
-  const int ng = (frame_off[u + 1] - frame_off[u] + 15) / 16, lt = T - tile_first[u];
-  const int nj = ng - 4 * lt < 4 ? ng - 4 * lt : 4;
   if (f >= F) return;
-  const float* src = part16 + ((size_t)(g0 + 4 * lt) * slots + slot) * Fs + f;
+  const int g0 = tile_g0[T], nj = (tile_cnt[T] + 15) / 16;      // the tile's first group and its 1..4 groups (tables of vaenmf_bind_batch)
+  const float* src = part16 + ((size_t)g0 * slots + slot) * Fs + f;
   float v = src[0];
   for (int j = 1; j < nj; ++j) v += src[(size_t)j * slots * Fs];
   part64[((size_t)T * slots + slot) * Fs + f] = v;
@@ -457,8 +452,8 @@ int vn_launch_w_update_tiles(const vaenmf_plan* p, float* W, hipStream_t st, boo
   const int threads = ((p->Fs + 63) / 64) * 64;
   if (groups) {                                           // group sums -> tile partials (small batches)
     VN_REQUIRE(p->wpart16, "group partials: rank <= 8 only");
-    hipLaunchKernelGGL(w_combine_groups_kernel, dim3(p->n_t64, 2 * p->Kp), dim3(threads), 0, st, p->wpart16, p->d_t64_first, p->d_frame_off,
-                       p->n_utt, p->cfg.F, p->Fs, 2 * p->Kp, p->wpart64);
+    hipLaunchKernelGGL(w_combine_groups_kernel, dim3(p->n_t64, 2 * p->Kp), dim3(threads), 0, st, p->wpart16, p->d_t64_g0, p->d_t64_cnt,
+                       p->cfg.F, p->Fs, 2 * p->Kp, p->wpart64);
   }
   switch (p->Kp) {
     case 8: hipLaunchKernelGGL((w_update_tiles_kernel<8>), dim3(p->n_utt), dim3(threads), 0, st, p->wpart64, p->d_t64_first, W, p->normW, p->cfg.F, p->Fs, p->cfg.K); break;

@@ -65,9 +65,10 @@ struct vaenmf_plan {
   int n_wtiles;
   // tiles of <= 64 consecutive frames of one utterance (wstats_fused_kernel: one workgroup per tile) and the partial sums of
   // the W update, one [Fs][2 Kp] block per tile
-  int32_t *d_t64_n0 = nullptr, *d_t64_cnt = nullptr, *d_t64_first = nullptr;      // [n_t64], [n_t64], [n_utt+1]
+  int32_t *d_t64_n0 = nullptr, *d_t64_cnt = nullptr, *d_t64_first = nullptr, *d_t64_g0 = nullptr;      // [n_t64], [n_t64], [n_utt+1]
   int n_t64 = 0;
   float* wpart64 = nullptr;
+  size_t wpart16_groups = 0; // capacity of wpart16 in 16-frame groups
   float* wpart16 = nullptr;  // [n_sms][2 Kp][Fs]: per-16-frame-group partials of wstats_group_kernel (small batches, rank <= 8)
   int last_chain_kernel = 0; // VAENMF_Q_CHAIN_KERNEL
   int last_w_fused = 0;      // VAENMF_Q_W_FUSED: 1 when the last stored M-step ran the fused W-statistics kernel

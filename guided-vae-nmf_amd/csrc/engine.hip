@@ -1657,7 +1657,7 @@ extern "C" int vaenmf_em_run(vaenmf_plan* p, const float* X2, float* W, float* H
       (uint64_t)p->VsS_cap, (uint64_t)p->Rcap_store, u64(p->w1f), u64(p->w2f), u64(p->w3f), u64(p->w3c), u64(p->b3c), u64(p->b1),
       u64(p->d_wt_utt), u64(p->d_wt_n0), u64(p->d_wt_cnt), u64(p->d_frame_off), u64(p->d_frame_utt), u64(p->d_frame_loc), u64(p->d_tile_utt),
       u64(p->d_tile_n0), u64(p->d_tile_cnt), u64(p->d_utt_seed), u64(p->A1), u64(p->P), u64(p->normW), u64(p->wpart), u64(p->cost_frames), u64(p->w3n), u64(p->w1y), u64(p->b2), u64(p->b3),
-      u64(p->wpart64), u64(p->wpart16), u64(p->d_t64_n0), u64(p->d_t64_cnt), u64(p->d_t64_first), (uint64_t)p->n_t64,
+      u64(p->wpart64), u64(p->wpart16), u64(p->d_t64_n0), u64(p->d_t64_cnt), u64(p->d_t64_first), u64(p->d_t64_g0), (uint64_t)p->n_t64,
       (uint64_t)p->cfg.precision, (uint64_t)p->cfg.K, (uint64_t)p->cfg.F};
   auto after_replay = [&]() {                           // the host-side state an eager call leaves behind
     if (stored) { p->store_R = nsWF; p->store_Rs = nsWF + 1; }

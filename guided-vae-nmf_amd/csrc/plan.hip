@@ -163,9 +163,13 @@ extern "C" int vaenmf_plan_create(const vaenmf_config* cfg, vaenmf_plan** out) {
   const size_t max_t64 = NTc / 64 + Uc + 1;
   e |= dev_alloc(&p->d_t64_n0, max_t64);
   e |= dev_alloc(&p->d_t64_cnt, max_t64);
+  e |= dev_alloc(&p->d_t64_g0, max_t64);
   e |= dev_alloc(&p->d_t64_first, Uc + 1);
   e |= dev_alloc(&p->wpart64, max_t64 * p->Fs * 2 * p->Kp);
-  if (p->Kp == 8) e |= dev_alloc(&p->wpart16, (size_t)p->n_sms * p->Fs * 2 * p->Kp);
+  if (p->Kp == 8) {       // group partials of small batches (at most one 16-frame group per CU)
+    p->wpart16_groups = (size_t)p->n_sms;
+    e |= dev_alloc(&p->wpart16, p->wpart16_groups * p->Fs * 2 * p->Kp);
+  }
   if (e) { vaenmf_plan_destroy(p); return -2; }
   *out = p;
   return 0;
@@ -175,7 +179,7 @@ extern "C" void vaenmf_plan_destroy(vaenmf_plan* p) {
   if (!p) return;
   void* ptrs[] = {p->w1f, p->w2f, p->w3f, p->b1, p->b2, p->b3, p->w3n, p->w1y, p->d_frame_off, p->d_tile_utt, p->d_tile_n0,
                   p->d_tile_cnt, p->d_frame_utt, p->d_frame_loc, p->d_utt_seed, p->A1, p->P, p->normW, p->wpart, p->cost_frames,
-                  p->VsS, p->src, p->w3c, p->b3c, p->d_wt_utt, p->d_wt_n0, p->d_wt_cnt, p->d_t64_n0, p->d_t64_cnt, p->d_t64_first,
+                  p->VsS, p->src, p->w3c, p->b3c, p->d_wt_utt, p->d_wt_n0, p->d_wt_cnt, p->d_t64_n0, p->d_t64_cnt, p->d_t64_first, p->d_t64_g0,
                   p->wpart64, p->wpart16};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -312,13 +316,16 @@ extern "C" int vaenmf_bind_batch_async(vaenmf_plan* p, int32_t n_utt, const int3
         w_n0.push_back(n);
         w_cnt.push_back(frame_offsets[u + 1] - n < 16 ? frame_offsets[u + 1] - n : 16);
       }
-    std::vector<int32_t> t64_n0, t64_cnt, t64_first(n_utt + 1);   // <= 64-frame tiles of the fused W-statistics kernel
+    std::vector<int32_t> t64_n0, t64_cnt, t64_g0, t64_first(n_utt + 1);   // <= 64-frame tiles of the fused W-statistics kernel
+    int32_t gcount = 0;                                   // 16-frame groups (= wave tiles) before the utterance
     for (int u = 0; u < n_utt; ++u) {
       t64_first[u] = (int32_t)t64_n0.size();
       for (int n = frame_offsets[u]; n < frame_offsets[u + 1]; n += 64) {
         t64_n0.push_back(n);
         t64_cnt.push_back(frame_offsets[u + 1] - n < 64 ? frame_offsets[u + 1] - n : 64);
+        t64_g0.push_back(gcount + (n - frame_offsets[u]) / 16);       // the tile's first group (w_combine_groups_kernel)
       }
+      gcount += (frame_offsets[u + 1] - frame_offsets[u] + 15) / 16;
     }
     t64_first[n_utt] = (int32_t)t64_n0.size();
     VN_CHECK_HIP(hipStreamSynchronize(st));               // kernels of the previous batch may still read the tables
@@ -334,6 +341,7 @@ extern "C" int vaenmf_bind_batch_async(vaenmf_plan* p, int32_t n_utt, const int3
     e |= upload(p->d_wt_cnt, w_cnt.data(), w_cnt.size());
     e |= upload(p->d_t64_n0, t64_n0.data(), t64_n0.size());
     e |= upload(p->d_t64_cnt, t64_cnt.data(), t64_cnt.size());
+    e |= upload(p->d_t64_g0, t64_g0.data(), t64_g0.size());
     e |= upload(p->d_t64_first, t64_first.data(), t64_first.size());
     p->n_t64 = (int)t64_n0.size();
     if (e) return -2;

@@ -1252,14 +1252,16 @@ __global__ __launch_bounds__(256, 2) void wstats_fused_kernel(const StreamArgs a
 // the cost come out bit-identical to the large-batch path (tested), so an utterance's result still does not depend on the
 // batch it sits in.
 // ----------------------------------------------------------------------------
-template <int KP, int RT>
+// (ST = float, the bf16x3 mode's rows, was measured too: no gain over wstats_stream + w_partial at any batch size -- 131.9 against
+// 132.4 ms per step, 46.0 against 45.5 ms for one utterance -- and is not instantiated.)
+template <int KP, int RT, typename ST>
 __global__ __launch_bounds__(256, 2) void wstats_group_kernel(const StreamArgs a, const int32_t* __restrict__ wt_n0,
                                                               const int32_t* __restrict__ wt_cnt, int n_groups, float* __restrict__ part16) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  FrameCtx<1, KP, __bf16> fc(a, wlds);
+  FrameCtx<1, KP, ST> fc(a, wlds);
   float* acc = wlds + (size_t)a.Fs * KP;                  // [slot = 2 k + stat][lane][4 bins], then 2 x 64 floats for the extra bin
-  using RBt = RowBatch<1, __bf16, 1, RT>;
+  using RBt = RowBatch<1, ST, 1, RT, (sizeof(ST) == 4 ? 32 : 0)>;
   const unsigned l4 = (unsigned)fc.lane * 4u;
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const int g_n0 = wt_n0[grp], g_cnt = wt_cnt[grp];
@@ -1284,7 +1286,7 @@ __global__ __launch_bounds__(256, 2) void wstats_group_kernel(const StreamArgs a
       a1xs[i] = pxs[i] = hls[i] = 0.f;
       const int n = n_beg + i;
       if (n < n_end) {
-        const __bf16* base = reinterpret_cast<const __bf16*>(a.VsS) + (size_t)n * a.Rs * a.Fs;
+        const ST* base = reinterpret_cast<const ST*>(a.VsS) + (size_t)n * a.Rs * a.Fs;
         const int sl = RBt::load_slots(fc, a.src + n, 0, RT);
         const float gn = a.g[n];
         f32x4 x2[1];
@@ -1509,8 +1511,8 @@ bool w_group_ok(const vaenmf_plan* p) {
 int launch_w_group(const vaenmf_plan* p, StreamArgs a, hipStream_t st) {
   const size_t lds = ((size_t)a.Fs * 8 + (size_t)wf_acc_floats<8>()) * sizeof(float);
   const int grid = p->n_wtiles;
-  if (a.R == 30) hipLaunchKernelGGL((wstats_group_kernel<8, 30>), dim3(grid), dim3(256), lds, st, a, p->d_wt_n0, p->d_wt_cnt, p->n_wtiles, p->wpart16);
-  else hipLaunchKernelGGL((wstats_group_kernel<8, 10>), dim3(grid), dim3(256), lds, st, a, p->d_wt_n0, p->d_wt_cnt, p->n_wtiles, p->wpart16);
+  if (a.R == 30) hipLaunchKernelGGL((wstats_group_kernel<8, 30, __bf16>), dim3(grid), dim3(256), lds, st, a, p->d_wt_n0, p->d_wt_cnt, p->n_wtiles, p->wpart16);
+  else hipLaunchKernelGGL((wstats_group_kernel<8, 10, __bf16>), dim3(grid), dim3(256), lds, st, a, p->d_wt_n0, p->d_wt_cnt, p->n_wtiles, p->wpart16);
   VN_CHECK_HIP(hipGetLastError());
   return 0;
 }
